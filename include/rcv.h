@@ -1,0 +1,222 @@
+/*
+ * rcv.h -- C ABI of librcv.so, the MI355X (gfx950) implementation of the RoboCupVision
+ * ROBO-UNet / U-Net training hot path.
+ *
+ * The reference (szemenyeim/RoboCupVision) has no FFI of its own: its hot path bottoms out in
+ * PyTorch ATen operators called from model.py / train.py.  This header is therefore the boundary
+ * a maintainer would bind *instead of* those operator calls; every entry point names the
+ * reference call site it replaces (file:line into the reference repository).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and integers only.  No torch / C++ types cross the boundary.
+ *   - Every function returns 0 on success, a negative RCV_E_* code on failure; the text of the
+ *     last failure on the calling thread is returned by rcv_last_error().  Nothing throws.
+ *   - All pointers are device pointers BORROWED for the duration of the call (they must stay valid
+ *     until the work enqueued on `stream` has completed).  The library never allocates device
+ *     memory: outputs and workspaces are passed in; sizes come from rcv_op_workspace().
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).  All work is
+ *     enqueued asynchronously on it; nothing here synchronises the device (graph-capture safe).
+ *   - Activations are fp32 NHWC ([N][H][W][C], C contiguous).  The network input (images) and the
+ *     network output (logits) are fp32 NCHW, as the reference's callers hand over / expect.
+ *   - All reductions are fixed-order (no float atomics): results are bitwise reproducible.
+ *
+ * Execution model: the host describes each kernel invocation as one `rcv_op` record; a whole
+ * forward or backward pass is an array of records executed by ONE call to rcv_run() (one host
+ * call per pass instead of one per layer; the records are plain data and may be cached).
+ * The named entry points further down are conveniences that fill a record and run it.
+ */
+#ifndef RCV_H
+#define RCV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RCV_VERSION 100
+
+/* error codes */
+#define RCV_OK            0
+#define RCV_E_ARG        -1   /* bad argument / unsupported shape */
+#define RCV_E_HIP        -2   /* a HIP runtime call failed        */
+#define RCV_E_UNSUPPORTED -3
+
+typedef struct rcv_handle rcv_handle;
+
+int  rcv_create(int device, rcv_handle** out);
+int  rcv_destroy(rcv_handle* h);
+const char* rcv_last_error(void);
+int  rcv_version(void);
+/* Multiprocessor (CU) count of the handle's device; used by callers to size split-K. */
+int  rcv_num_cus(const rcv_handle* h);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Operation records                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* kinds */
+enum {
+  RCV_OP_CONV        = 1,  /* 3x3 gather convolution (implicit GEMM on MFMA)                     */
+  RCV_OP_TCONV       = 2,  /* 3x3 stride-2 transposed convolution, pad 1, output_padding 1       */
+  RCV_OP_WGRAD       = 3,  /* 3x3 filter gradient, split over pixels, partials to workspace      */
+  RCV_OP_WGRAD_REDUCE= 4,  /* fixed-order sum of WGRAD partials -> parameter-layout gradient     */
+  RCV_OP_PACK        = 5,  /* parameter tensors -> kernel filter layout, table driven            */
+  RCV_OP_BN_FINALIZE = 6,  /* batch statistics -> scale/shift (+ running stats)                  */
+  RCV_OP_BN_EVAL     = 7,  /* running statistics -> scale/shift                                  */
+  RCV_OP_BN_BWD      = 8,  /* backward reductions -> (A,B,C) constants, dgamma, dbeta            */
+  RCV_OP_COMBINE     = 9,  /* up = relu(t*s+h) + (r*s2+h2)          (decoder skip add)           */
+  RCV_OP_CLS_FWD     = 10, /* 1x1 classifier, NHWC in -> NCHW logits                             */
+  RCV_OP_CLS_BWD     = 11, /* classifier backward (dgrad + wgrad + dbias) from NCHW dlogits      */
+  RCV_OP_CE_FWD      = 12, /* weighted softmax cross-entropy forward (+argmax, +#correct)        */
+  RCV_OP_CE_BWD      = 13, /* d loss / d logits                                                  */
+  RCV_OP_POOL_FWD    = 14, /* 2x2/2 max-pool of (r*s+h)                                          */
+  RCV_OP_POOL_BWD    = 15, /* max-pool backward (+skip gradient, + BN backward reductions)       */
+  RCV_OP_ADAM_L1     = 16, /* fused Adam step with decay*sign(p) L1 gradient over a flat buffer  */
+  RCV_OP_MEMSET      = 17, /* zero a float buffer                                                */
+  RCV_OP_CONV1X1     = 18, /* generic 1x1 convolution NHWC -> NHWC/NCHW (LabelProp classifier)   */
+  RCV_OP_ADD_SLICE   = 19, /* x[..., 0:Ca] += affine(a)   (LabelProp top skip, model.py:565)     */
+  RCV_OP_MATERIALIZE = 20, /* out = load(in)  (a block's normalised output as a plain tensor)    */
+  RCV_OP_BWD_STATS   = 21  /* out = g; partial rows of the BN-backward sums of g against e       */
+};
+
+/* how an operand is produced from memory while it is staged (rcv_op.i[RCV_I_INMODE] etc.) */
+enum {
+  RCV_LOAD_PLAIN    = 0,   /* v = x                                                              */
+  RCV_LOAD_AFFINE   = 1,   /* v = x*c0[ch] + c1[ch]                (BatchNorm apply of producer) */
+  RCV_LOAD_GRAD_ENC = 2,   /* v = aux>0 ? c0*x + c1 + c2*aux : 0   (BN-bwd then ReLU-bwd)        */
+  RCV_LOAD_GRAD_DEC = 3,   /* v = c0*(aux*c3+c4>0 ? x : 0) + c1 + c2*aux   (ReLU-bwd then BN-bwd)*/
+  RCV_LOAD_NCHW     = 4,   /* v = x, tensor is NCHW (network input image)                        */
+  RCV_LOAD_AFFINE_RELU = 5 /* v = max(x*c0+c1, 0)               (conv->BN->ReLU producer)        */
+};
+
+/* epilogue statistics written as per-workgroup partial rows [n_part][2][C] */
+enum {
+  RCV_STATS_NONE   = 0,
+  RCV_STATS_FWD    = 1,    /* sum v, sum v*v                     (BatchNorm batch statistics)    */
+  RCV_STATS_BWD_ENC= 2,    /* sum g, sum g*e      e = epi_aux    (BN backward, conv->ReLU->BN)   */
+  RCV_STATS_BWD_DEC= 3     /* sum g*m, sum g*m*e  m = (e*c0+c1>0) (BN backward, convT->BN->ReLU) */
+};
+
+/* flag bits (rcv_op.flags) */
+#define RCV_F_BIAS      1u    /* add bias[co]                                                     */
+#define RCV_F_RELU      2u    /* clamp at zero after bias                                         */
+#define RCV_F_RESID     4u    /* add resid[...] (same shape as the output) before stats/store     */
+#define RCV_F_OUT_NCHW  8u    /* CONV1X1 / CLS: store NCHW                                        */
+#define RCV_F_FLIP      16u   /* PACK: reverse the 3x3 taps                                       */
+#define RCV_F_TRANSPOSED_SRC 32u /* PACK / WGRAD_REDUCE: parameter is [Cin][Cout][3][3] (convT)  */
+#define RCV_F_ARGMAX    64u   /* CE_FWD: also write argmax mask and count correct pixels          */
+#define RCV_F_TRAINING  128u  /* BN_FINALIZE: update running stats                                */
+
+/* integer slots */
+enum {
+  RCV_I_N = 0, RCV_I_H, RCV_I_W,          /* spatial dims of the gathered (input) tensor          */
+  RCV_I_CIN, RCV_I_COUT,
+  RCV_I_HO, RCV_I_WO,                     /* spatial dims of the output tensor                    */
+  RCV_I_STRIDE, RCV_I_DIL,
+  RCV_I_INMODE,                           /* RCV_LOAD_* of operand `in`                           */
+  RCV_I_INMODE2,                          /* WGRAD: RCV_LOAD_* of the pointwise operand           */
+  RCV_I_STATS,                            /* RCV_STATS_*                                          */
+  RCV_I_NPART,                            /* rows of `part` (filled by rcv_op_workspace)          */
+  RCV_I_NSPLIT,                           /* WGRAD: pixel splits (filled by rcv_op_workspace)     */
+  RCV_I_COUNT,                            /* element / job count for table driven ops             */
+  RCV_I_AUX0, RCV_I_AUX1,
+  RCV_I__N = 20
+};
+
+/* pointer slots */
+enum {
+  RCV_P_IN = 0,      /* gathered operand                                                          */
+  RCV_P_IN_AUX,      /* second tensor of a GRAD_* load                                            */
+  RCV_P_IN_C,        /* per-channel constants of the load: float[5][C] planar (c0..c4)            */
+  RCV_P_W,           /* packed filter / parameter                                                 */
+  RCV_P_BIAS,
+  RCV_P_OUT,
+  RCV_P_RESID,
+  RCV_P_EPI_AUX,     /* tensor e of the BWD statistics                                            */
+  RCV_P_EPI_C,       /* float[2][C]: (c0,c1) of RCV_STATS_BWD_DEC                                 */
+  RCV_P_PART,        /* partial rows                                                              */
+  RCV_P_IN2,         /* WGRAD: pointwise operand                                                  */
+  RCV_P_IN2_AUX,
+  RCV_P_IN2_C,
+  RCV_P_X0, RCV_P_X1, RCV_P_X2, RCV_P_X3, RCV_P_X4, RCV_P_X5,   /* kind specific            */
+  RCV_P__N = 20
+};
+
+typedef struct rcv_op {
+  int32_t  kind;
+  uint32_t flags;
+  int32_t  i[RCV_I__N];
+  float    f[8];
+  void*    p[RCV_P__N];
+} rcv_op;
+
+/* Fills op->i[RCV_I_NPART] / [RCV_I_NSPLIT] for the tiling the library will use and returns
+ * the bytes of the `part` workspace the op needs (0 if none). */
+int rcv_op_workspace(const rcv_handle* h, rcv_op* op, size_t* part_bytes);
+
+/* Enqueue ops[0..n) in order on `stream`. */
+int rcv_run(rcv_handle* h, const rcv_op* ops, int n, void* stream);
+
+/* One row of the RCV_OP_PACK job table (device memory, p[RCV_P_IN] -> rcv_pack_job[count]). */
+typedef struct rcv_pack_job {
+  const float* src;   /* parameter tensor [D0][D1][3][3]                                          */
+  float*       dst;   /* [9][rows_pad][cols_pad], zero filled pads                                */
+  int32_t D0, D1;
+  int32_t rows_from_d1;   /* 1: rows (contraction channel) = d1, cols = d0; 0: rows = d0, cols=d1 */
+  int32_t flip;           /* 1: tap t reads source tap 8-t                                        */
+  int32_t rows_pad, cols_pad;
+} rcv_pack_job;
+
+/* ------------------------------------------------------------------------------------------ */
+/* Named entry points (each = fill one record + rcv_run).  Reference call sites they replace:  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* nn.Conv2d(k=3,pad=dil,stride,dilation) forward, fused bias / ReLU / BN statistics, optional
+ * BatchNorm-apply of the producer folded into the load.   model.py:112,115-116; model.py:170,175
+ * Also the data gradient of a stride-1 conv (flipped, transposed filter) and of the transposed
+ * conv (aten::convolution_backward under train.py:57).                                          */
+int rcv_conv3x3(rcv_handle* h, const rcv_op* op, void* stream);
+/* nn.ConvTranspose2d(k=3,s=2,p=1,output_padding=1) forward (model.py:186-187,191) and the data
+ * gradient of a stride-2 conv.                                                                  */
+int rcv_convT3x3s2(rcv_handle* h, const rcv_op* op, void* stream);
+/* filter gradients of both (aten::convolution_backward).                                        */
+int rcv_wgrad3x3(rcv_handle* h, const rcv_op* op, void* stream);
+
+/* nn.BatchNorm2d train-mode statistics -> normalisation constants (model.py:113,116,189,192).   *
+ *   part [n_part][2][C] -> scale,shift (float[5][C] slot layout c0,c1), mean, istd, running.    */
+int rcv_bn_finalize(rcv_handle* h, const float* part, int n_part, int C, double count,
+                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, int training,
+                    float* consts /*[5][C]*/, float* save_mean, float* save_istd, void* stream);
+/* aten::native_batch_norm_backward reductions -> load constants for RCV_LOAD_GRAD_*.            */
+int rcv_bn_backward(rcv_handle* h, const float* part, int n_part, int C, double count,
+                    const float* gamma, const float* save_mean, const float* save_istd,
+                    const float* fwd_consts, int decoder,
+                    float* consts /*[5][C]*/, float* dgamma, float* dbeta, void* stream);
+
+/* nn.MaxPool2d(2,2) of the normalised producer (model.py:97-100).                               */
+int rcv_maxpool2x2_fwd(rcv_handle* h, const float* r, const float* consts, float* out,
+                       int N, int H, int W, int C, void* stream);
+
+/* CrossEntropyLoss2d (model.py:76-82) + torch.max(pred,1) / pixel accuracy (train.py:70-71).    *
+ *   logits NCHW, target int64 [N][H][W]; loss_out[0]=loss, [1]=sum_w, [2]=#correct (as float).  */
+int rcv_softmax_ce_argmax_fwd(rcv_handle* h, const float* logits, const int64_t* target,
+                              const float* class_weight /*may be NULL*/, int N, int C, int H, int W,
+                              float* part, int n_part, float* loss_out, uint8_t* argmax /*may be NULL*/,
+                              void* stream);
+int rcv_softmax_ce_bwd(rcv_handle* h, const float* logits, const int64_t* target,
+                       const float* class_weight, const float* loss_out, const float* grad_out,
+                       int N, int C, int H, int W, float* dlogits, void* stream);
+
+/* train.py:23-27,52-55 (decay * L1 -> gradient decay*sign(p)) + torch.optim.Adam.step            *
+ * (train.py:67,357-363) over one flat fp32 buffer; lr is per element group via lr_scale[].      */
+int rcv_adam_l1_step(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                     const float* lr_elem /*may be NULL*/, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float decay, int step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RCV_H */

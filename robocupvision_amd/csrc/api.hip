@@ -1,0 +1,181 @@
+// C ABI of librcv.so (declared in include/rcv.h): handle, error text, op dispatch and the named
+// convenience entry points.  Nothing here allocates device memory or synchronises the device.
+#include <stdarg.h>
+#include <string.h>
+#include "rcv_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void rcv_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" {
+
+const char* rcv_last_error(void) { return g_err; }
+int rcv_version(void) { return RCV_VERSION; }
+
+int rcv_create(int device, rcv_handle** out) {
+  RCV_CHECK_ARG(out != nullptr, "rcv_create: out is NULL");
+  int count = 0;
+  RCV_HIP(hipGetDeviceCount(&count));
+  RCV_CHECK_ARG(device >= 0 && device < count, "rcv_create: device %d out of range (%d visible)", device, count);
+  hipDeviceProp_t prop;
+  RCV_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    rcv_set_error("rcv_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    return RCV_E_UNSUPPORTED;
+  }
+  rcv_handle* h = new rcv_handle;
+  h->device = device;
+  h->num_cus = prop.multiProcessorCount;
+  h->max_lds = 160 * 1024;
+  *out = h;
+  return RCV_OK;
+}
+
+int rcv_destroy(rcv_handle* h) {
+  delete h;
+  return RCV_OK;
+}
+
+int rcv_num_cus(const rcv_handle* h) { return h ? h->num_cus : 0; }
+
+static int dispatch(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* q) {
+  switch (op->kind) {
+    case RCV_OP_CONV:
+    case RCV_OP_TCONV:
+      return rcv_launch_conv(h, op, s, q);
+    case RCV_OP_WGRAD:
+    case RCV_OP_WGRAD_REDUCE:
+      return rcv_launch_wgrad(h, op, s, q);
+    default:
+      return rcv_launch_small(h, op, s, q);
+  }
+}
+
+int rcv_op_workspace(const rcv_handle* h, rcv_op* op, size_t* part_bytes) {
+  RCV_CHECK_ARG(h && op && part_bytes, "rcv_op_workspace: NULL argument");
+  OpQuery q = {0, 0, 0};
+  const int rc = dispatch(h, op, nullptr, &q);
+  if (rc) return rc;
+  op->i[RCV_I_NPART] = q.n_part;
+  if (op->kind == RCV_OP_WGRAD) op->i[RCV_I_NSPLIT] = q.n_split;
+  *part_bytes = q.part_bytes;
+  return RCV_OK;
+}
+
+int rcv_run(rcv_handle* h, const rcv_op* ops, int n, void* stream) {
+  RCV_CHECK_ARG(h && (ops || n == 0) && n >= 0, "rcv_run: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  for (int k = 0; k < n; ++k) {
+    const int rc = dispatch(h, &ops[k], s, nullptr);
+    if (rc) {
+      char tmp[400];
+      strncpy(tmp, g_err, sizeof(tmp) - 1);
+      tmp[sizeof(tmp) - 1] = 0;
+      rcv_set_error("op %d (kind %d): %s", k, ops[k].kind, tmp);
+      return rc;
+    }
+  }
+  return RCV_OK;
+}
+
+// ------------------------------ named entry points ------------------------------
+int rcv_conv3x3(rcv_handle* h, const rcv_op* op, void* stream) {
+  RCV_CHECK_ARG(op && op->kind == RCV_OP_CONV, "rcv_conv3x3: record kind must be RCV_OP_CONV");
+  return rcv_run(h, op, 1, stream);
+}
+int rcv_convT3x3s2(rcv_handle* h, const rcv_op* op, void* stream) {
+  RCV_CHECK_ARG(op && op->kind == RCV_OP_TCONV, "rcv_convT3x3s2: record kind must be RCV_OP_TCONV");
+  return rcv_run(h, op, 1, stream);
+}
+int rcv_wgrad3x3(rcv_handle* h, const rcv_op* op, void* stream) {
+  RCV_CHECK_ARG(op && op->kind == RCV_OP_WGRAD, "rcv_wgrad3x3: record kind must be RCV_OP_WGRAD");
+  return rcv_run(h, op, 1, stream);
+}
+
+int rcv_bn_finalize(rcv_handle* h, const float* part, int n_part, int C, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, int training, float* consts,
+                    float* save_mean, float* save_istd, void* stream) {
+  RCV_CHECK_ARG(count == (double)(long long)count && count < 2147483647.0, "rcv_bn_finalize: count must be an integer < 2^31");
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_BN_FINALIZE;
+  op.flags = training ? RCV_F_TRAINING : 0;
+  op.i[RCV_I_N] = (int)count; op.i[RCV_I_HO] = 1; op.i[RCV_I_WO] = 1;
+  op.i[RCV_I_COUT] = C; op.i[RCV_I_NPART] = n_part;
+  op.f[0] = momentum; op.f[1] = eps;
+  op.p[RCV_P_PART] = (void*)part; op.p[RCV_P_OUT] = consts;
+  op.p[RCV_P_X0] = (void*)gamma; op.p[RCV_P_X1] = (void*)beta; op.p[RCV_P_X2] = running_mean; op.p[RCV_P_X3] = running_var;
+  op.p[RCV_P_X4] = save_mean; op.p[RCV_P_X5] = save_istd;
+  return rcv_run(h, &op, 1, stream);
+}
+
+int rcv_bn_backward(rcv_handle* h, const float* part, int n_part, int C, double count, const float* gamma, const float* save_mean,
+                    const float* save_istd, const float* fwd_consts, int decoder, float* consts, float* dgamma, float* dbeta,
+                    void* stream) {
+  (void)decoder;
+  RCV_CHECK_ARG(count == (double)(long long)count && count < 2147483647.0, "rcv_bn_backward: count must be an integer < 2^31");
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_BN_BWD;
+  op.i[RCV_I_N] = (int)count; op.i[RCV_I_HO] = 1; op.i[RCV_I_WO] = 1;
+  op.i[RCV_I_COUT] = C; op.i[RCV_I_NPART] = n_part;
+  op.p[RCV_P_PART] = (void*)part; op.p[RCV_P_OUT] = consts; op.p[RCV_P_IN_C] = (void*)fwd_consts;
+  op.p[RCV_P_X0] = (void*)gamma; op.p[RCV_P_X1] = dgamma; op.p[RCV_P_X2] = dbeta;
+  op.p[RCV_P_X4] = (void*)save_mean; op.p[RCV_P_X5] = (void*)save_istd;
+  return rcv_run(h, &op, 1, stream);
+}
+
+int rcv_maxpool2x2_fwd(rcv_handle* h, const float* r, const float* consts, float* out, int N, int H, int W, int C, void* stream) {
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_POOL_FWD;
+  op.i[RCV_I_N] = N; op.i[RCV_I_H] = H; op.i[RCV_I_W] = W; op.i[RCV_I_COUT] = C;
+  op.i[RCV_I_INMODE] = consts ? RCV_LOAD_AFFINE : RCV_LOAD_PLAIN;
+  op.p[RCV_P_IN] = (void*)r; op.p[RCV_P_IN_C] = (void*)consts; op.p[RCV_P_OUT] = out;
+  return rcv_run(h, &op, 1, stream);
+}
+
+int rcv_softmax_ce_argmax_fwd(rcv_handle* h, const float* logits, const int64_t* target, const float* class_weight, int N, int C,
+                              int H, int W, float* part, int n_part, float* loss_out, uint8_t* argmax, void* stream) {
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_CE_FWD;
+  op.flags = argmax ? RCV_F_ARGMAX : 0;
+  op.i[RCV_I_N] = N; op.i[RCV_I_H] = H; op.i[RCV_I_W] = W; op.i[RCV_I_COUT] = C; op.i[RCV_I_NPART] = n_part;
+  op.p[RCV_P_IN] = (void*)logits; op.p[RCV_P_IN2] = (void*)target; op.p[RCV_P_W] = (void*)class_weight;
+  op.p[RCV_P_PART] = part; op.p[RCV_P_OUT] = loss_out; op.p[RCV_P_X0] = argmax;
+  return rcv_run(h, &op, 1, stream);
+}
+
+int rcv_softmax_ce_bwd(rcv_handle* h, const float* logits, const int64_t* target, const float* class_weight, const float* loss_out,
+                       const float* grad_out, int N, int C, int H, int W, float* dlogits, void* stream) {
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_CE_BWD;
+  op.i[RCV_I_N] = N; op.i[RCV_I_H] = H; op.i[RCV_I_W] = W; op.i[RCV_I_COUT] = C;
+  op.p[RCV_P_IN] = (void*)logits; op.p[RCV_P_IN2] = (void*)target; op.p[RCV_P_W] = (void*)class_weight;
+  op.p[RCV_P_X0] = (void*)loss_out; op.p[RCV_P_X1] = (void*)grad_out; op.p[RCV_P_OUT] = dlogits;
+  return rcv_run(h, &op, 1, stream);
+}
+
+int rcv_adam_l1_step(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* lr_elem,
+                     int64_t n, float lr, float beta1, float beta2, float eps, float decay, int step, float grad_scale,
+                     void* stream) {
+  RCV_CHECK_ARG(n > 0 && n < 2147483647LL, "rcv_adam_l1_step: n out of range");
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_ADAM_L1;
+  op.i[RCV_I_COUNT] = (int)n; op.i[RCV_I_AUX0] = step;
+  op.f[0] = lr; op.f[1] = beta1; op.f[2] = beta2; op.f[3] = eps; op.f[4] = decay; op.f[5] = grad_scale;
+  op.p[RCV_P_IN] = param; op.p[RCV_P_IN2] = (void*)grad; op.p[RCV_P_X0] = exp_avg; op.p[RCV_P_X1] = exp_avg_sq;
+  op.p[RCV_P_X2] = (void*)lr_elem;
+  return rcv_run(h, &op, 1, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// Internal declarations shared by the librcv translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/rcv.h"
+
+struct rcv_handle {
+  int device;
+  int num_cus;
+  int max_lds;   // bytes of LDS one workgroup may use
+};
+
+void rcv_set_error(const char* fmt, ...);
+
+#define RCV_CHECK_ARG(cond, ...)                         \
+  do {                                                   \
+    if (!(cond)) {                                       \
+      rcv_set_error(__VA_ARGS__);                        \
+      return RCV_E_ARG;                                  \
+    }                                                    \
+  } while (0)
+
+#define RCV_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      rcv_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return RCV_E_HIP;                                                                \
+    }                                                                                  \
+  } while (0)
+
+// Exact n / d for 0 <= n < 65536, 1 <= d < 65536 (m = floor(2^32/d)+1; d == 1 handled apart).
+struct FastDiv {
+  uint32_t m, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  f.m = (d <= 1) ? 0u : (uint32_t)((0x100000000ull / d) + 1ull);
+  return f;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t fd_div(uint32_t n, FastDiv f) {
+  return f.d == 1 ? n : __umulhi(n, f.m);
+}
+#endif
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// ---- launchers implemented in the .hip files; each validates, picks a tiling and enqueues ----
+// `query` != nullptr: do not launch, only fill tiling dependent outputs (n_part / n_split / bytes).
+struct OpQuery {
+  int n_part;
+  int n_split;
+  size_t part_bytes;
+};
+int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query);
+int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query);
+int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query);

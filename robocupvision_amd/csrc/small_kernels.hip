@@ -1,0 +1,776 @@
+// Memory-bound and bookkeeping kernels of the ROBO-UNet step (everything that is not a 3x3
+// contraction).  All of them are HBM-bound streaming kernels or tiny per-channel reductions:
+// 16-byte NHWC vector accesses, plane-coalesced NCHW accesses for the image / logits, wave
+// shuffles + fixed-order LDS trees for the reductions (no float atomics).
+#include "rcv_internal.h"
+
+__device__ __forceinline__ float4 sld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void sst4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// RCV_OP_PACK: parameter [D0][D1][3][3] -> [9][rows_pad][cols_pad] (zero padded), table driven
+// ------------------------------------------------------------------------------------------
+__global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
+  const rcv_pack_job jb = jobs[blockIdx.y];
+  const int per_tap = jb.rows_pad * jb.cols_pad;
+  const int total = 9 * per_tap;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int t = e / per_tap;
+    const int rc = e - t * per_tap;
+    const int row = rc / jb.cols_pad, col = rc - row * jb.cols_pad;
+    const int rows = jb.rows_from_d1 ? jb.D1 : jb.D0;
+    const int cols = jb.rows_from_d1 ? jb.D0 : jb.D1;
+    float v = 0.f;
+    if (row < rows && col < cols) {
+      const int d0 = jb.rows_from_d1 ? col : row;
+      const int d1 = jb.rows_from_d1 ? row : col;
+      const int ts = jb.flip ? 8 - t : t;
+      v = jb.src[((size_t)d0 * jb.D1 + d1) * 9 + ts];
+    }
+    jb.dst[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm bookkeeping (one workgroup per channel; double accumulation over the partial rows)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_sum2_d(double& a, double& b) {
+  __shared__ double sh[2][8];
+  a = wave_sum_d(a);
+  b = wave_sum_d(b);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[0][w] = a; sh[1][w] = b; }
+  __syncthreads();
+  a = 0.0; b = 0.0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { a += sh[0][i]; b += sh[1][i]; }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int n_part, int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
+                                   float eps, int training, float* consts, float* save_mean, float* save_istd) {
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
+    s1 += (double)part[((size_t)i * 2 + 0) * C + c];
+    s2 += (double)part[((size_t)i * 2 + 1) * C + c];
+  }
+  block_sum2_d(s1, s2);
+  if (threadIdx.x == 0) {
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * istd;
+    consts[0 * C + c] = sc;
+    consts[1 * C + c] = beta[c] - (float)mean * sc;
+    consts[2 * C + c] = 0.f; consts[3 * C + c] = 0.f; consts[4 * C + c] = 0.f;
+    save_mean[c] = (float)mean;
+    save_istd[c] = istd;
+    if (training && running_mean) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+__global__ void bn_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rm, const float* __restrict__ rv, float eps, float* consts) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    const float istd = 1.f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * istd;
+    consts[0 * C + c] = sc;
+    consts[1 * C + c] = beta[c] - rm[c] * sc;
+    consts[2 * C + c] = 0.f; consts[3 * C + c] = 0.f; consts[4 * C + c] = 0.f;
+  }
+}
+
+// dr = A*g + B + C*r  with  A = gamma*istd,  C = -A*istd*Sgx/M,  B = -A*Sg/M - C*mean,
+// Sgx = istd*(Sgr - mean*Sg);  dgamma = Sgx, dbeta = Sg.   (aten::native_batch_norm_backward)
+__global__ void bn_bwd_kernel(const float* __restrict__ part, int n_part, int C, double count, const float* __restrict__ gamma,
+                              const float* __restrict__ save_mean, const float* __restrict__ save_istd,
+                              const float* __restrict__ fwd_consts, float* consts, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
+    s1 += (double)part[((size_t)i * 2 + 0) * C + c];
+    s2 += (double)part[((size_t)i * 2 + 1) * C + c];
+  }
+  block_sum2_d(s1, s2);
+  if (threadIdx.x == 0) {
+    const double mean = save_mean[c], istd = save_istd[c];
+    const double sgx = istd * (s2 - mean * s1);
+    const double A = (double)gamma[c] * istd;
+    const double Cc = -A * istd * sgx / count;
+    const double B = -A * s1 / count - Cc * mean;
+    consts[0 * C + c] = (float)A;
+    consts[1 * C + c] = (float)B;
+    consts[2 * C + c] = (float)Cc;
+    consts[3 * C + c] = fwd_consts[0 * C + c];
+    consts[4 * C + c] = fwd_consts[1 * C + c];
+    if (dgamma) dgamma[c] = (float)sgx;
+    if (dbeta) dbeta[c] = (float)s1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// RCV_OP_COMBINE: up = relu(t*c0+c1) + f(r)   f = affine / affine+relu / identity  (model.py:509)
+// ------------------------------------------------------------------------------------------
+template <int MODE2>
+__global__ void combine_kernel(const float* __restrict__ t, const float* __restrict__ tc, const float* __restrict__ r,
+                               const float* __restrict__ rc, float* __restrict__ out, size_t n4, int C) {
+  const int C4 = C / 4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(e % C4) * 4;
+    const float4 a = sld4(t + e * 4), s = sld4(tc + ch), h = sld4(tc + C + ch);
+    float4 v;
+    v.x = fmaxf(fmaf(a.x, s.x, h.x), 0.f); v.y = fmaxf(fmaf(a.y, s.y, h.y), 0.f);
+    v.z = fmaxf(fmaf(a.z, s.z, h.z), 0.f); v.w = fmaxf(fmaf(a.w, s.w, h.w), 0.f);
+    float4 b = sld4(r + e * 4);
+    if (MODE2 != RCV_LOAD_PLAIN) {
+      const float4 s2 = sld4(rc + ch), h2 = sld4(rc + C + ch);
+      b.x = fmaf(b.x, s2.x, h2.x); b.y = fmaf(b.y, s2.y, h2.y); b.z = fmaf(b.z, s2.z, h2.z); b.w = fmaf(b.w, s2.w, h2.w);
+      if (MODE2 == RCV_LOAD_AFFINE_RELU) { b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f); }
+    }
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    sst4(out + e * 4, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// 1x1 classifier (model.py:411): NHWC [.,CIN] -> NCHW logits [N][COUT][H][W]
+// ------------------------------------------------------------------------------------------
+#define CLS_MAX_OUT 8
+template <int CIN>
+__global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                               float* __restrict__ out, int N, int HW, int COUT) {
+  __shared__ float ws[CLS_MAX_OUT * CIN + CLS_MAX_OUT];
+  for (int e = threadIdx.x; e < COUT * CIN; e += blockDim.x) ws[e] = w[e];
+  for (int e = threadIdx.x; e < COUT; e += blockDim.x) ws[CLS_MAX_OUT * CIN + e] = bias ? bias[e] : 0.f;
+  __syncthreads();
+  const size_t total = (size_t)N * HW;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+    float v[CIN];
+#pragma unroll
+    for (int q = 0; q < CIN / 4; ++q) {
+      const float4 a = sld4(x + p * CIN + 4 * q);
+      v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+    }
+    const size_t n = p / HW, hw = p % HW;
+#pragma unroll
+    for (int c = 0; c < CLS_MAX_OUT; ++c) {
+      if (c < COUT) {
+        float u = ws[CLS_MAX_OUT * CIN + c];
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) u = fmaf(v[k], ws[c * CIN + k], u);
+        out[(n * COUT + c) * HW + hw] = u;
+      }
+    }
+  }
+}
+
+// classifier backward: d_up[p][k] = sum_c dl[c][p] W[c][k];  dW[c][k] = sum_p dl[c][p] up[p][k];
+// db[c] = sum_p dl[c][p];  optional decoder BN-backward statistics of d_up against t.
+template <int CIN, int COUT>
+__global__ void cls_bwd_kernel(const float* __restrict__ up, const float* __restrict__ dl, const float* __restrict__ w,
+                               float* __restrict__ dup, const float* __restrict__ t, const float* __restrict__ tc,
+                               float* __restrict__ stat_part, float* __restrict__ w_part, int N, int HW, int stats) {
+  __shared__ float ws[COUT * CIN];
+  __shared__ float red[4][COUT * CIN + COUT + 2 * CIN];
+  for (int e = threadIdx.x; e < COUT * CIN; e += blockDim.x) ws[e] = w[e];
+  __syncthreads();
+  float dw[COUT][CIN], db[COUT], s1[CIN], s2[CIN];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) { db[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) dw[c][k] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < CIN; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+  const size_t total = (size_t)N * HW;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = p / HW, hw = p % HW;
+    float g[COUT], u[CIN], d[CIN];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) g[c] = dl[(n * COUT + c) * HW + hw];
+#pragma unroll
+    for (int q = 0; q < CIN / 4; ++q) {
+      const float4 a = sld4(up + p * CIN + 4 * q);
+      u[4 * q] = a.x; u[4 * q + 1] = a.y; u[4 * q + 2] = a.z; u[4 * q + 3] = a.w;
+    }
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) acc = fmaf(g[c], ws[c * CIN + k], acc);
+      d[k] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < CIN / 4; ++q) sst4(dup + p * CIN + 4 * q, make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]));
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+      db[c] += g[c];
+#pragma unroll
+      for (int k = 0; k < CIN; ++k) dw[c][k] = fmaf(g[c], u[k], dw[c][k]);
+    }
+    if (stats == RCV_STATS_BWD_DEC) {
+#pragma unroll
+      for (int q = 0; q < CIN / 4; ++q) {
+        const float4 a = sld4(t + p * CIN + 4 * q);
+        const float tv[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 4 * q + j;
+          const float gm = fmaf(tv[j], tc[k], tc[CIN + k]) > 0.f ? d[k] : 0.f;
+          s1[k] += gm;
+          s2[k] = fmaf(gm, tv[j], s2[k]);
+        }
+      }
+    }
+  }
+  // block reduction: wave shuffles, then the 4 waves through LDS in fixed order
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) {
+#pragma unroll
+    for (int k = 0; k < CIN; ++k) { const float v = wave_sum(dw[c][k]); if (lane == 0) red[wv][c * CIN + k] = v; }
+    const float v = wave_sum(db[c]);
+    if (lane == 0) red[wv][COUT * CIN + c] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < CIN; ++k) {
+    const float v1 = wave_sum(s1[k]), v2 = wave_sum(s2[k]);
+    if (lane == 0) { red[wv][COUT * CIN + COUT + k] = v1; red[wv][COUT * CIN + COUT + CIN + k] = v2; }
+  }
+  __syncthreads();
+  const int nw = blockDim.x >> 6;
+  for (int e = threadIdx.x; e < COUT * CIN + COUT + 2 * CIN; e += blockDim.x) {
+    float v = 0.f;
+    for (int i = 0; i < nw; ++i) v += red[i][e];
+    if (e < COUT * CIN + COUT) w_part[(size_t)blockIdx.x * (COUT * CIN + COUT) + e] = v;
+    else if (stats == RCV_STATS_BWD_DEC) stat_part[(size_t)blockIdx.x * 2 * CIN + (e - COUT * CIN - COUT)] = v;
+  }
+}
+
+__global__ void rows_reduce_kernel(const float* __restrict__ part, int n_rows, int width, float* __restrict__ out0, int n0,
+                                   float* __restrict__ out1) {
+  // out0[e] (e < n0) and out1[e-n0] = sum over rows, fixed order, double accumulation
+  const int e = blockIdx.x;
+  double s = 0.0, dummy = 0.0;
+  for (int i = threadIdx.x; i < n_rows; i += blockDim.x) s += (double)part[(size_t)i * width + e];
+  block_sum2_d(s, dummy);
+  if (threadIdx.x == 0) {
+    if (e < n0) out0[e] = (float)s;
+    else if (out1) out1[e - n0] = (float)s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CrossEntropyLoss2d (model.py:76-82) + argmax / pixel accuracy (train.py:70-71)
+// ------------------------------------------------------------------------------------------
+#define CE_MAX_C 8
+__global__ void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, const float* __restrict__ cw,
+                              int N, int C, int HW, float* __restrict__ part, uint8_t* __restrict__ argmax) {
+  __shared__ double sh[3][4];
+  double a_nll = 0.0, a_w = 0.0, a_ok = 0.0;
+  const size_t total = (size_t)N * HW;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = p / HW, hw = p % HW;
+    float v[CE_MAX_C];
+    float mx = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c) {
+      if (c < C) {
+        v[c] = logits[(n * C + c) * HW + hw];
+        if (v[c] > mx) { mx = v[c]; am = c; }   // strict '>' : first maximum wins (torch.max semantics)
+      }
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c) if (c < C) se += expf(v[c] - mx);
+    const int tg = (int)target[p];
+    float vt = 0.f;
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c) if (c == tg) vt = v[c];
+    const float w = cw ? cw[tg] : 1.f;
+    const float nll = (mx - vt) + logf(se);
+    a_nll += (double)(w * nll);
+    a_w += (double)w;
+    a_ok += (am == tg) ? 1.0 : 0.0;
+    if (argmax) argmax[p] = (uint8_t)am;
+  }
+  a_nll = wave_sum_d(a_nll); a_w = wave_sum_d(a_w); a_ok = wave_sum_d(a_ok);
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[0][wv] = a_nll; sh[1][wv] = a_w; sh[2][wv] = a_ok; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    double s = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sh[threadIdx.x][i];
+    part[(size_t)blockIdx.x * 3 + threadIdx.x] = (float)s;
+  }
+}
+
+__global__ void ce_finalize_kernel(const float* __restrict__ part, int n_part, float* __restrict__ loss_out) {
+  __shared__ double sh[3][4];
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
+    s[0] += (double)part[(size_t)i * 3 + 0]; s[1] += (double)part[(size_t)i * 3 + 1]; s[2] += (double)part[(size_t)i * 3 + 2];
+  }
+  const int wv = threadIdx.x >> 6;
+  for (int j = 0; j < 3; ++j) { s[j] = wave_sum_d(s[j]); if ((threadIdx.x & 63) == 0) sh[j][wv] = s[j]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t[3] = {0.0, 0.0, 0.0};
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t[j] += sh[j][i];
+    loss_out[0] = (float)(t[0] / t[1]);
+    loss_out[1] = (float)t[1];
+    loss_out[2] = (float)t[2];
+    loss_out[3] = (float)t[0];
+  }
+}
+
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, const float* __restrict__ cw,
+                              const float* __restrict__ loss_out, const float* __restrict__ grad_out, int N, int C, int HW,
+                              float* __restrict__ dlogits) {
+  const float scale = grad_out[0] / loss_out[1];
+  const size_t total = (size_t)N * HW;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = p / HW, hw = p % HW;
+    float v[CE_MAX_C];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c) if (c < C) { v[c] = logits[(n * C + c) * HW + hw]; mx = fmaxf(mx, v[c]); }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c) if (c < C) { v[c] = expf(v[c] - mx); se += v[c]; }
+    const int tg = (int)target[p];
+    const float k = scale * (cw ? cw[tg] : 1.f);
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c)
+      if (c < C) dlogits[(n * C + c) * HW + hw] = k * (v[c] * inv - (c == tg ? 1.f : 0.f));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool2d(2,2) (model.py:97-100) of y = r*c0+c1, and its backward fused with the skip-gradient
+// add and the BatchNorm-backward reductions of the producer.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void pool_fwd_kernel(const float* __restrict__ r, const float* __restrict__ cst, float* __restrict__ out, int N, int H,
+                                int W, int C) {
+  const int C4 = C / 4, Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(e % C4);
+    size_t pp = e / C4;
+    const int ox = (int)(pp % Wo); pp /= Wo;
+    const int oy = (int)(pp % Ho);
+    const int n = (int)(pp / Ho);
+    float4 s = make_float4(1.f, 1.f, 1.f, 1.f), h = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE != RCV_LOAD_PLAIN) { s = sld4(cst + 4 * q); h = sld4(cst + C + 4 * q); }
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float4 v = sld4(r + (((size_t)n * H + 2 * oy + dy) * W + 2 * ox + dx) * C + 4 * q);
+        v.x = fmaf(v.x, s.x, h.x); v.y = fmaf(v.y, s.y, h.y); v.z = fmaf(v.z, s.z, h.z); v.w = fmaf(v.w, s.w, h.w);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    sst4(out + e * 4, m);
+  }
+}
+
+// dy (full res) = scatter(dp -> first arg-max of the 2x2 window) [+ skip grad]; partial rows of
+// (sum dy, sum dy*r) per workgroup.  blockDim.x must be a multiple of C/4.
+template <int MODE>
+__global__ void pool_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ r, const float* __restrict__ cst,
+                                const float* __restrict__ resid, float* __restrict__ dy, float* __restrict__ part, int N, int H,
+                                int W, int C, int stats) {
+  extern __shared__ float4 sh4[];
+  const int C4 = C / 4, Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  const int q = threadIdx.x % C4;
+  float4 s = make_float4(1.f, 1.f, 1.f, 1.f), h = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE != RCV_LOAD_PLAIN) { s = sld4(cst + 4 * q); h = sld4(cst + C + 4 * q); }
+  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    size_t pp = e / C4;
+    const int ox = (int)(pp % Wo); pp /= Wo;
+    const int oy = (int)(pp % Ho);
+    const int n = (int)(pp / Ho);
+    const float4 g = sld4(dp + e * 4);
+    float4 rv[4];
+    float bx = -INFINITY, by = -INFINITY, bz = -INFINITY, bw = -INFINITY;
+    int ix = 0, iy = 0, iz = 0, iw = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rv[j] = sld4(r + (((size_t)n * H + 2 * oy + (j >> 1)) * W + 2 * ox + (j & 1)) * C + 4 * q);
+      const float vx = fmaf(rv[j].x, s.x, h.x), vy = fmaf(rv[j].y, s.y, h.y), vz = fmaf(rv[j].z, s.z, h.z), vw = fmaf(rv[j].w, s.w, h.w);
+      if (vx > bx) { bx = vx; ix = j; }
+      if (vy > by) { by = vy; iy = j; }
+      if (vz > bz) { bz = vz; iz = j; }
+      if (vw > bw) { bw = vw; iw = j; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t off = (((size_t)n * H + 2 * oy + (j >> 1)) * W + 2 * ox + (j & 1)) * C + 4 * q;
+      float4 v = make_float4(ix == j ? g.x : 0.f, iy == j ? g.y : 0.f, iz == j ? g.z : 0.f, iw == j ? g.w : 0.f);
+      if (resid) { const float4 rr = sld4(resid + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+      sst4(dy + off, v);
+      a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+      a2.x = fmaf(v.x, rv[j].x, a2.x); a2.y = fmaf(v.y, rv[j].y, a2.y); a2.z = fmaf(v.z, rv[j].z, a2.z); a2.w = fmaf(v.w, rv[j].w, a2.w);
+    }
+  }
+  if (stats != RCV_STATS_NONE) {
+    sh4[threadIdx.x] = a1;
+    sh4[blockDim.x + threadIdx.x] = a2;
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * C4) {
+      const int which = threadIdx.x / C4, qq = threadIdx.x % C4;
+      float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int e = qq; e < (int)blockDim.x; e += C4) { const float4 v = sh4[which * blockDim.x + e]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
+      sst4(part + ((size_t)blockIdx.x * 2 + which) * C + 4 * qq, u);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused optimizer step over one flat fp32 buffer: g = grad*grad_scale + decay*sign(p) (the
+// gradient of decay*sum|p|, train.py:23-27,53-55) followed by torch.optim.Adam's update
+// (train.py:67, defaults betas .9/.999 eps 1e-8, no weight decay, no amsgrad).
+// ------------------------------------------------------------------------------------------
+__global__ void adam_l1_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                               const float* __restrict__ lr_elem, size_t n, float lr, float b1, float b2, float eps, float decay,
+                               float grad_scale, float bc1, float bc2_sqrt) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float pv = p[e];
+    const float sg = pv > 0.f ? 1.f : (pv < 0.f ? -1.f : 0.f);
+    const float gr = fmaf(decay, sg, g[e] * grad_scale);
+    const float mm = b1 * m[e] + (1.f - b1) * gr;
+    const float vv = b2 * v[e] + (1.f - b2) * gr * gr;
+    m[e] = mm; v[e] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    const float step = (lr_elem ? lr_elem[e] : lr) / bc1;
+    p[e] = pv - step * (mm / denom);
+  }
+}
+
+__global__ void memset_kernel(float* __restrict__ p, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) p[e] = 0.f;
+}
+
+// x[..., 0:Ca] += f(a)   (LabelProp model.py:565; f = relu(affine) of the `pre` block)
+__global__ void add_slice_kernel(float* __restrict__ x, int C, const float* __restrict__ a, const float* __restrict__ ac, int Ca,
+                                 size_t npix, int mode) {
+  const int C4 = Ca / 4;
+  const size_t total = npix * C4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int q = (int)(e % C4);
+    const size_t p = e / C4;
+    float4 b = sld4(a + p * Ca + 4 * q);
+    if (mode != RCV_LOAD_PLAIN) {
+      const float4 s = sld4(ac + 4 * q), h = sld4(ac + Ca + 4 * q);
+      b.x = fmaf(b.x, s.x, h.x); b.y = fmaf(b.y, s.y, h.y); b.z = fmaf(b.z, s.z, h.z); b.w = fmaf(b.w, s.w, h.w);
+      if (mode == RCV_LOAD_AFFINE_RELU) { b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f); }
+    }
+    float4 v = sld4(x + p * C + 4 * q);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    sst4(x + p * C + 4 * q, v);
+  }
+}
+
+// out = f(in): a block's output as a plain NHWC tensor (block-level module calls, LabelProp tail)
+__global__ void materialize_kernel(const float* __restrict__ x, const float* __restrict__ c, float* __restrict__ out, size_t n4, int C,
+                                   int mode) {
+  const int C4 = C / 4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+    float4 v = sld4(x + e * 4);
+    if (mode != RCV_LOAD_PLAIN) {
+      const int ch = (int)(e % C4) * 4;
+      const float4 s = sld4(c + ch), h = sld4(c + C + ch);
+      v.x = fmaf(v.x, s.x, h.x); v.y = fmaf(v.y, s.y, h.y); v.z = fmaf(v.z, s.z, h.z); v.w = fmaf(v.w, s.w, h.w);
+      if (mode == RCV_LOAD_AFFINE_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    }
+    sst4(out + e * 4, v);
+  }
+}
+
+// out = g and per-workgroup partial rows (sum g[*m], sum g[*m]*e) -- the BatchNorm-backward sums when the
+// gradient arrives from outside the engine (block-level module calls).  blockDim.x % (C/4) == 0.
+__global__ void bwd_stats_kernel(const float* __restrict__ g, const float* __restrict__ ev, const float* __restrict__ ec,
+                                 float* __restrict__ out, float* __restrict__ part, size_t n4, int C, int stats) {
+  extern __shared__ float4 sh4[];
+  const int C4 = C / 4;
+  const int q = threadIdx.x % C4;
+  float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+  if (stats == RCV_STATS_BWD_DEC) { c0 = sld4(ec + 4 * q); c1 = sld4(ec + C + 4 * q); }
+  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+    float4 v = sld4(g + e * 4);
+    sst4(out + e * 4, v);
+    const float4 x = sld4(ev + e * 4);
+    if (stats == RCV_STATS_BWD_DEC) {
+      v.x = fmaf(x.x, c0.x, c1.x) > 0.f ? v.x : 0.f; v.y = fmaf(x.y, c0.y, c1.y) > 0.f ? v.y : 0.f;
+      v.z = fmaf(x.z, c0.z, c1.z) > 0.f ? v.z : 0.f; v.w = fmaf(x.w, c0.w, c1.w) > 0.f ? v.w : 0.f;
+    }
+    a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
+    a2.x = fmaf(v.x, x.x, a2.x); a2.y = fmaf(v.y, x.y, a2.y); a2.z = fmaf(v.z, x.z, a2.z); a2.w = fmaf(v.w, x.w, a2.w);
+  }
+  sh4[threadIdx.x] = a1;
+  sh4[blockDim.x + threadIdx.x] = a2;
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * C4) {
+    const int which = threadIdx.x / C4, qq = threadIdx.x % C4;
+    float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = qq; e < (int)blockDim.x; e += C4) { const float4 v = sh4[which * blockDim.x + e]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
+    sst4(part + ((size_t)blockIdx.x * 2 + which) * C + 4 * qq, u);
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// launcher
+// --------------------------------------------------------------------------------------------
+static inline int stream_grid(const rcv_handle* h, size_t work_items, int block) {
+  size_t g = (work_items + block - 1) / block;
+  const size_t cap = (size_t)h->num_cus * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// number of workgroups used by the reducing stream kernels (deterministic function of the shape)
+static inline int reduce_grid(const rcv_handle* h, size_t work_items, int block) {
+  size_t g = (work_items + block - 1) / block;
+  const size_t cap = (size_t)h->num_cus * 4;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query) {
+  const int N = op->i[RCV_I_N], H = op->i[RCV_I_H], W = op->i[RCV_I_W];
+  const int Cin = op->i[RCV_I_CIN], Cout = op->i[RCV_I_COUT];
+  if (query) { query->n_part = 0; query->n_split = 0; query->part_bytes = 0; }
+  switch (op->kind) {
+    case RCV_OP_PACK: {
+      if (query) return RCV_OK;
+      const int count = op->i[RCV_I_COUNT], max_elems = op->i[RCV_I_AUX0];
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && count > 0 && max_elems > 0, "pack: bad job table");
+      int gx = ceil_div(max_elems, 256);
+      if (gx > 64) gx = 64;
+      hipLaunchKernelGGL(pack_kernel, dim3(gx, count), dim3(256), 0, s, (const rcv_pack_job*)op->p[RCV_P_IN]);
+      break;
+    }
+    case RCV_OP_BN_FINALIZE: {
+      if (query) return RCV_OK;
+      const double count = (double)N * op->i[RCV_I_HO] * op->i[RCV_I_WO];
+      RCV_CHECK_ARG(op->p[RCV_P_PART] && op->p[RCV_P_OUT] && op->p[RCV_P_X0] && op->p[RCV_P_X1] && op->p[RCV_P_X4] && op->p[RCV_P_X5],
+                    "bn_finalize: null operand");
+      RCV_CHECK_ARG(op->i[RCV_I_NPART] > 0 && Cout > 0 && count > 0, "bn_finalize: empty");
+      hipLaunchKernelGGL(bn_finalize_kernel, dim3(Cout), dim3(256), 0, s, (const float*)op->p[RCV_P_PART], op->i[RCV_I_NPART], Cout, count,
+                         (const float*)op->p[RCV_P_X0], (const float*)op->p[RCV_P_X1], (float*)op->p[RCV_P_X2], (float*)op->p[RCV_P_X3],
+                         op->f[0], op->f[1], (op->flags & RCV_F_TRAINING) ? 1 : 0, (float*)op->p[RCV_P_OUT], (float*)op->p[RCV_P_X4],
+                         (float*)op->p[RCV_P_X5]);
+      break;
+    }
+    case RCV_OP_BN_EVAL: {
+      if (query) return RCV_OK;
+      RCV_CHECK_ARG(op->p[RCV_P_OUT] && op->p[RCV_P_X0] && op->p[RCV_P_X1] && op->p[RCV_P_X2] && op->p[RCV_P_X3], "bn_eval: null operand");
+      hipLaunchKernelGGL(bn_eval_kernel, dim3(ceil_div(Cout, 64)), dim3(64), 0, s, Cout, (const float*)op->p[RCV_P_X0],
+                         (const float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], (const float*)op->p[RCV_P_X3], op->f[1],
+                         (float*)op->p[RCV_P_OUT]);
+      break;
+    }
+    case RCV_OP_BN_BWD: {
+      if (query) return RCV_OK;
+      const double count = (double)N * op->i[RCV_I_HO] * op->i[RCV_I_WO];
+      RCV_CHECK_ARG(op->p[RCV_P_PART] && op->p[RCV_P_OUT] && op->p[RCV_P_X0] && op->p[RCV_P_X4] && op->p[RCV_P_X5] && op->p[RCV_P_IN_C],
+                    "bn_bwd: null operand");
+      hipLaunchKernelGGL(bn_bwd_kernel, dim3(Cout), dim3(256), 0, s, (const float*)op->p[RCV_P_PART], op->i[RCV_I_NPART], Cout, count,
+                         (const float*)op->p[RCV_P_X0], (const float*)op->p[RCV_P_X4], (const float*)op->p[RCV_P_X5],
+                         (const float*)op->p[RCV_P_IN_C], (float*)op->p[RCV_P_OUT], (float*)op->p[RCV_P_X1], (float*)op->p[RCV_P_X2]);
+      break;
+    }
+    case RCV_OP_COMBINE: {
+      if (query) return RCV_OK;
+      RCV_CHECK_ARG(Cout % 4 == 0 && op->p[RCV_P_IN] && op->p[RCV_P_IN_C] && op->p[RCV_P_IN2] && op->p[RCV_P_OUT], "combine: bad operand");
+      const size_t n4 = (size_t)N * H * W * Cout / 4;
+      const int g = stream_grid(h, n4, 256);
+      const int m2 = op->i[RCV_I_INMODE2];
+      RCV_CHECK_ARG(m2 == RCV_LOAD_PLAIN || op->p[RCV_P_IN2_C], "combine: skip constants missing");
+      if (m2 == RCV_LOAD_PLAIN)
+        hipLaunchKernelGGL(combine_kernel<RCV_LOAD_PLAIN>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN_C], (const float*)op->p[RCV_P_IN2], (const float*)op->p[RCV_P_IN2_C], (float*)op->p[RCV_P_OUT], n4, Cout);
+      else if (m2 == RCV_LOAD_AFFINE)
+        hipLaunchKernelGGL(combine_kernel<RCV_LOAD_AFFINE>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN_C], (const float*)op->p[RCV_P_IN2], (const float*)op->p[RCV_P_IN2_C], (float*)op->p[RCV_P_OUT], n4, Cout);
+      else
+        hipLaunchKernelGGL(combine_kernel<RCV_LOAD_AFFINE_RELU>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN_C], (const float*)op->p[RCV_P_IN2], (const float*)op->p[RCV_P_IN2_C], (float*)op->p[RCV_P_OUT], n4, Cout);
+      break;
+    }
+    case RCV_OP_CLS_FWD: {
+      if (query) return RCV_OK;
+      RCV_CHECK_ARG((Cin == 8 || Cin == 16) && Cout >= 1 && Cout <= CLS_MAX_OUT, "classifier: Cin=%d Cout=%d unsupported", Cin, Cout);
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_W] && op->p[RCV_P_OUT], "classifier: null operand");
+      const int g = stream_grid(h, (size_t)N * H * W, 256);
+      if (Cin == 8)
+        hipLaunchKernelGGL(cls_fwd_kernel<8>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout);
+      else
+        hipLaunchKernelGGL(cls_fwd_kernel<16>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout);
+      break;
+    }
+    case RCV_OP_CLS_BWD: {
+      // partial rows: stats [g][2][Cin] in p[PART]; filter+bias [g][Cout*Cin+Cout] in p[X0]; then reduced in-op
+      const int g = reduce_grid(h, (size_t)N * H * W, 256);
+      const size_t wrow = (size_t)Cout * Cin + Cout;
+      if (query) {
+        query->n_part = g;
+        query->part_bytes = (size_t)g * (2 * Cin + wrow) * sizeof(float);
+        return RCV_OK;
+      }
+      RCV_CHECK_ARG(Cin == 8 && Cout == 5, "classifier backward: only 8 -> 5 is built (got %d -> %d)", Cin, Cout);
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_W] && op->p[RCV_P_OUT] && op->p[RCV_P_PART] && op->p[RCV_P_X1],
+                    "classifier backward: null operand");
+      RCV_CHECK_ARG(op->i[RCV_I_NPART] == g, "classifier backward: workspace rows %d != %d", op->i[RCV_I_NPART], g);
+      const int stats = op->i[RCV_I_STATS];
+      RCV_CHECK_ARG(stats == RCV_STATS_NONE || (op->p[RCV_P_EPI_AUX] && op->p[RCV_P_EPI_C]), "classifier backward: stats operands missing");
+      float* stat_part = (float*)op->p[RCV_P_PART];
+      float* w_part = stat_part + (size_t)g * 2 * Cin;
+      hipLaunchKernelGGL((cls_bwd_kernel<8, 5>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
+                         (const float*)op->p[RCV_P_W], (float*)op->p[RCV_P_OUT], (const float*)op->p[RCV_P_EPI_AUX],
+                         (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats);
+      RCV_HIP(hipGetLastError());
+      // dW -> p[X1] ([Cout][Cin]), db -> p[X2]
+      hipLaunchKernelGGL(rows_reduce_kernel, dim3((int)wrow), dim3(256), 0, s, w_part, g, (int)wrow, (float*)op->p[RCV_P_X1], Cout * Cin,
+                         (float*)op->p[RCV_P_X2]);
+      break;
+    }
+    case RCV_OP_CE_FWD: {
+      const int HW = H * W;
+      const int g = reduce_grid(h, (size_t)N * HW, 256);
+      if (query) { query->n_part = g; query->part_bytes = (size_t)g * 3 * sizeof(float); return RCV_OK; }
+      RCV_CHECK_ARG(Cout >= 1 && Cout <= CE_MAX_C, "cross entropy: %d classes unsupported (max %d)", Cout, CE_MAX_C);
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_PART] && op->p[RCV_P_OUT], "cross entropy: null operand");
+      RCV_CHECK_ARG(op->i[RCV_I_NPART] == g, "cross entropy: workspace rows %d != %d", op->i[RCV_I_NPART], g);
+      hipLaunchKernelGGL(ce_fwd_kernel, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const int64_t*)op->p[RCV_P_IN2],
+                         (const float*)op->p[RCV_P_W], N, Cout, HW, (float*)op->p[RCV_P_PART],
+                         (op->flags & RCV_F_ARGMAX) ? (uint8_t*)op->p[RCV_P_X0] : nullptr);
+      RCV_HIP(hipGetLastError());
+      hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)op->p[RCV_P_PART], g, (float*)op->p[RCV_P_OUT]);
+      break;
+    }
+    case RCV_OP_CE_BWD: {
+      if (query) return RCV_OK;
+      RCV_CHECK_ARG(Cout >= 1 && Cout <= CE_MAX_C, "cross entropy: %d classes unsupported", Cout);
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_X0] && op->p[RCV_P_X1] && op->p[RCV_P_OUT], "cross entropy backward: null operand");
+      const int g = stream_grid(h, (size_t)N * H * W, 256);
+      hipLaunchKernelGGL(ce_bwd_kernel, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const int64_t*)op->p[RCV_P_IN2],
+                         (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_X0], (const float*)op->p[RCV_P_X1], N, Cout, H * W,
+                         (float*)op->p[RCV_P_OUT]);
+      break;
+    }
+    case RCV_OP_POOL_FWD: {
+      if (query) return RCV_OK;
+      RCV_CHECK_ARG(Cout % 4 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool: C=%d H=%d W=%d unsupported", Cout, H, W);
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_OUT], "maxpool: null operand");
+      const int g = stream_grid(h, (size_t)N * (H / 2) * (W / 2) * (Cout / 4), 256);
+      if (op->i[RCV_I_INMODE] == RCV_LOAD_PLAIN)
+        hipLaunchKernelGGL(pool_fwd_kernel<RCV_LOAD_PLAIN>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN_C], (float*)op->p[RCV_P_OUT], N, H, W, Cout);
+      else {
+        RCV_CHECK_ARG(op->p[RCV_P_IN_C], "maxpool: constants missing");
+        hipLaunchKernelGGL(pool_fwd_kernel<RCV_LOAD_AFFINE>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN_C], (float*)op->p[RCV_P_OUT], N, H, W, Cout);
+      }
+      break;
+    }
+    case RCV_OP_POOL_BWD: {
+      RCV_CHECK_ARG(Cout % 4 == 0 && Cout <= 512 && 256 % (Cout / 4) == 0 && H % 2 == 0 && W % 2 == 0, "maxpool backward: C=%d H=%d W=%d unsupported", Cout, H, W);
+      const int g = reduce_grid(h, (size_t)N * (H / 2) * (W / 2) * (Cout / 4), 256);
+      const int stats = op->i[RCV_I_STATS];
+      if (query) {
+        query->n_part = stats != RCV_STATS_NONE ? g : 0;
+        query->part_bytes = (size_t)query->n_part * 2 * Cout * sizeof(float);
+        return RCV_OK;
+      }
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_EPI_AUX] && op->p[RCV_P_OUT], "maxpool backward: null operand");
+      RCV_CHECK_ARG(stats == RCV_STATS_NONE || (op->p[RCV_P_PART] && op->i[RCV_I_NPART] == g), "maxpool backward: workspace rows mismatch");
+      const float* resid = (op->flags & RCV_F_RESID) ? (const float*)op->p[RCV_P_RESID] : nullptr;
+      const size_t lds = 2 * 256 * sizeof(float4);
+      if (op->i[RCV_I_INMODE] == RCV_LOAD_PLAIN)
+        hipLaunchKernelGGL(pool_bwd_kernel<RCV_LOAD_PLAIN>, dim3(g), dim3(256), lds, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_EPI_AUX], (const float*)op->p[RCV_P_IN_C], resid, (float*)op->p[RCV_P_OUT], (float*)op->p[RCV_P_PART], N, H, W, Cout, stats);
+      else {
+        RCV_CHECK_ARG(op->p[RCV_P_IN_C], "maxpool backward: constants missing");
+        hipLaunchKernelGGL(pool_bwd_kernel<RCV_LOAD_AFFINE>, dim3(g), dim3(256), lds, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_EPI_AUX], (const float*)op->p[RCV_P_IN_C], resid, (float*)op->p[RCV_P_OUT], (float*)op->p[RCV_P_PART], N, H, W, Cout, stats);
+      }
+      break;
+    }
+    case RCV_OP_ADAM_L1: {
+      if (query) return RCV_OK;
+      const size_t n = (size_t)(uint32_t)op->i[RCV_I_COUNT];
+      const int step = op->i[RCV_I_AUX0];
+      RCV_CHECK_ARG(n > 0 && step >= 1 && op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_X0] && op->p[RCV_P_X1], "adam: bad operand");
+      const float b1 = op->f[1], b2 = op->f[2];
+      const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
+      const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)step));
+      hipLaunchKernelGGL(adam_l1_kernel, dim3(stream_grid(h, n, 256)), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
+                         (float*)op->p[RCV_P_X0], (float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], n, op->f[0], b1, b2, op->f[3],
+                         op->f[4], op->f[5], bc1, bc2s);
+      break;
+    }
+    case RCV_OP_MEMSET: {
+      if (query) return RCV_OK;
+      const size_t n = (size_t)(uint32_t)op->i[RCV_I_COUNT];
+      RCV_CHECK_ARG(op->p[RCV_P_OUT] && n > 0, "memset: bad operand");
+      hipLaunchKernelGGL(memset_kernel, dim3(stream_grid(h, n, 256)), dim3(256), 0, s, (float*)op->p[RCV_P_OUT], n);
+      break;
+    }
+    case RCV_OP_ADD_SLICE: {
+      if (query) return RCV_OK;
+      const int Ca = Cin;
+      RCV_CHECK_ARG(Ca % 4 == 0 && Cout % 4 == 0 && Ca <= Cout && op->p[RCV_P_OUT] && op->p[RCV_P_IN], "add_slice: bad operand");
+      const size_t npix = (size_t)N * H * W;
+      hipLaunchKernelGGL(add_slice_kernel, dim3(stream_grid(h, npix * (Ca / 4), 256)), dim3(256), 0, s, (float*)op->p[RCV_P_OUT], Cout,
+                         (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN_C], Ca, npix, op->i[RCV_I_INMODE]);
+      break;
+    }
+    case RCV_OP_MATERIALIZE: {
+      if (query) return RCV_OK;
+      RCV_CHECK_ARG(Cout % 4 == 0 && op->p[RCV_P_IN] && op->p[RCV_P_OUT], "materialize: bad operand");
+      RCV_CHECK_ARG(op->i[RCV_I_INMODE] == RCV_LOAD_PLAIN || op->p[RCV_P_IN_C], "materialize: constants missing");
+      const size_t n4 = (size_t)N * H * W * Cout / 4;
+      hipLaunchKernelGGL(materialize_kernel, dim3(stream_grid(h, n4, 256)), dim3(256), 0, s, (const float*)op->p[RCV_P_IN],
+                         (const float*)op->p[RCV_P_IN_C], (float*)op->p[RCV_P_OUT], n4, Cout, op->i[RCV_I_INMODE]);
+      break;
+    }
+    case RCV_OP_BWD_STATS: {
+      RCV_CHECK_ARG(Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0, "bwd_stats: C=%d unsupported", Cout);
+      const size_t n4 = (size_t)N * H * W * Cout / 4;
+      const int g = reduce_grid(h, n4, 256);
+      const int stats = op->i[RCV_I_STATS];
+      if (query) { query->n_part = g; query->part_bytes = (size_t)g * 2 * Cout * sizeof(float); return RCV_OK; }
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_EPI_AUX] && op->p[RCV_P_OUT] && op->p[RCV_P_PART], "bwd_stats: null operand");
+      RCV_CHECK_ARG(stats != RCV_STATS_BWD_DEC || op->p[RCV_P_EPI_C], "bwd_stats: decoder constants missing");
+      RCV_CHECK_ARG(op->i[RCV_I_NPART] == g, "bwd_stats: workspace rows %d != %d", op->i[RCV_I_NPART], g);
+      hipLaunchKernelGGL(bwd_stats_kernel, dim3(g), dim3(256), 2 * 256 * sizeof(float4), s, (const float*)op->p[RCV_P_IN],
+                         (const float*)op->p[RCV_P_EPI_AUX], (const float*)op->p[RCV_P_EPI_C], (float*)op->p[RCV_P_OUT],
+                         (float*)op->p[RCV_P_PART], n4, Cout, stats);
+      break;
+    }
+    default:
+      rcv_set_error("unknown op kind %d", op->kind);
+      return RCV_E_ARG;
+  }
+  RCV_HIP(hipGetLastError());
+  return RCV_OK;
+}

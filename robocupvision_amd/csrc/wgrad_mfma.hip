@@ -1,0 +1,425 @@
+// 3x3 filter gradient on the gfx950 fp32 matrix cores (v_mfma_f32_16x16x4_f32), split over pixels.
+//
+//   dW[cb][ca][tap] = sum_p  P[p][cb] * G[s*p + tap*d - d][ca]
+//
+//   conv layer  (model.py:112):  G = layer input  (BN of the producer applied on load, zero padded),
+//                                P = dz, the gradient at the conv output (BN/ReLU backward on load);
+//                                dW is [Cout][Cin][3][3], db[cb] = sum_p P[p][cb].
+//   convT layer (model.py:186):  G = dt, the gradient at the 2x output (zero padded), stride 2,
+//                                P = layer input; dW is [Cin][Cout][3][3] -- the same index formula.
+//
+// GEMM mapping per tap:  D[cb][ca] += A[cb][k] * B[k][ca],  k = pixel (4 consecutive pixels of a tile
+// row per MFMA).  Both tiles sit in LDS channel-contiguous ([pixel][C + pad]); the pads make the two
+// pixels of a 32-lane group land on disjoint banks.  A wave keeps all nine taps of its
+// (WM x WN) x 16x16 channel tile in registers (9*WM*WN*4 VGPRs) and walks pixel tiles; workgroups
+// write partial filters [split][tap][cb][ca] that RCV_OP_WGRAD_REDUCE sums in a fixed order (no
+// float atomics => bitwise reproducible gradients).
+#include "rcv_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradArgs {
+  const float* g; const float* g_aux; const float* g_c;
+  const float* p; const float* p_aux; const float* p_c;
+  float* part;        // [nsplit][9][CBP][CAP]
+  float* part_bias;   // [nsplit][CBP] or null
+  int g_mode, p_mode;
+  int N, H, W, Hp, Wp, CA, CB, CAP, CBP;
+  int stride, dil;
+  int R, Wt, Wt4, tiles_x, tiles_y, ntiles, IH, IW, SP, SG;
+  int nsplit;
+  int pl_floats;      // floats of the P tile (G tile follows)
+  FastDiv fdWt4, fdIW;
+};
+
+__device__ __forceinline__ float4 wld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+template <int MODE>
+__device__ __forceinline__ float4 wxform4(float4 x, float4 a, const float4 (&k)[5]) {
+  float4 v;
+  if (MODE == RCV_LOAD_PLAIN) {
+    v = x;
+  } else if (MODE == RCV_LOAD_AFFINE) {
+    v.x = fmaf(x.x, k[0].x, k[1].x); v.y = fmaf(x.y, k[0].y, k[1].y);
+    v.z = fmaf(x.z, k[0].z, k[1].z); v.w = fmaf(x.w, k[0].w, k[1].w);
+  } else if (MODE == RCV_LOAD_AFFINE_RELU) {
+    v.x = fmaxf(fmaf(x.x, k[0].x, k[1].x), 0.f); v.y = fmaxf(fmaf(x.y, k[0].y, k[1].y), 0.f);
+    v.z = fmaxf(fmaf(x.z, k[0].z, k[1].z), 0.f); v.w = fmaxf(fmaf(x.w, k[0].w, k[1].w), 0.f);
+  } else if (MODE == RCV_LOAD_GRAD_ENC) {
+    v.x = a.x > 0.f ? fmaf(k[0].x, x.x, fmaf(k[2].x, a.x, k[1].x)) : 0.f;
+    v.y = a.y > 0.f ? fmaf(k[0].y, x.y, fmaf(k[2].y, a.y, k[1].y)) : 0.f;
+    v.z = a.z > 0.f ? fmaf(k[0].z, x.z, fmaf(k[2].z, a.z, k[1].z)) : 0.f;
+    v.w = a.w > 0.f ? fmaf(k[0].w, x.w, fmaf(k[2].w, a.w, k[1].w)) : 0.f;
+  } else {
+    v.x = fmaf(k[0].x, (fmaf(a.x, k[3].x, k[4].x) > 0.f ? x.x : 0.f), fmaf(k[2].x, a.x, k[1].x));
+    v.y = fmaf(k[0].y, (fmaf(a.y, k[3].y, k[4].y) > 0.f ? x.y : 0.f), fmaf(k[2].y, a.y, k[1].y));
+    v.z = fmaf(k[0].z, (fmaf(a.z, k[3].z, k[4].z) > 0.f ? x.z : 0.f), fmaf(k[2].z, a.z, k[1].z));
+    v.w = fmaf(k[0].w, (fmaf(a.w, k[3].w, k[4].w) > 0.f ? x.w : 0.f), fmaf(k[2].w, a.w, k[1].w));
+  }
+  return v;
+}
+
+// Stage a [rows x cols] pixel window of an NHWC tensor (C channels, tile channels [c0, c0+CT)) into
+// dst[pixel][SD]; out-of-image pixels and channels >= C are zero (AFTER the transform).
+template <int MODE, int CT, int NT>
+__device__ __forceinline__ float4 stage_tile(const float* src, const float* aux, const float* cst, int C, int Himg, int Wimg,
+                                             int n, int gy0, int gx0, int rows_valid, int cols_valid, int rows, int cols,
+                                             FastDiv fdcols, int c0, float* dst, int SD, int tid) {
+  constexpr int Q = CT / 4;
+  const int q = tid % Q;
+  const int ch = c0 + 4 * q;
+  const bool ch_ok = ch < C;
+  float4 k[5];
+  if (MODE != RCV_LOAD_PLAIN && ch_ok) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) k[j] = wld4(cst + (size_t)j * C + ch);
+  }
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int npix = rows * cols;
+  for (int pix = tid / Q; pix < npix; pix += NT / Q) {
+    const int iy = fd_div(pix, fdcols), ix = pix - iy * cols;
+    const int gy = gy0 + iy, gx = gx0 + ix;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ch_ok && iy < rows_valid && ix < cols_valid && (unsigned)gy < (unsigned)Himg && (unsigned)gx < (unsigned)Wimg) {
+      const size_t off = ((size_t)(n * Himg + gy) * Wimg + gx) * C + ch;
+      const float4 x = wld4(src + off);
+      float4 a = x;
+      if (MODE == RCV_LOAD_GRAD_ENC || MODE == RCV_LOAD_GRAD_DEC) a = wld4(aux + off);
+      v = wxform4<MODE>(x, a, k);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dst + pix * SD + 4 * q) = v;
+  }
+  return sum;
+}
+
+template <int CT, int NT>
+__device__ __forceinline__ float4 stage_dispatch(int mode, const float* src, const float* aux, const float* cst, int C, int Himg,
+                                                 int Wimg, int n, int gy0, int gx0, int rows_valid, int cols_valid, int rows,
+                                                 int cols, FastDiv fdcols, int c0, float* dst, int SD, int tid) {
+  switch (mode) {
+    case RCV_LOAD_PLAIN: return stage_tile<RCV_LOAD_PLAIN, CT, NT>(src, aux, cst, C, Himg, Wimg, n, gy0, gx0, rows_valid, cols_valid, rows, cols, fdcols, c0, dst, SD, tid);
+    case RCV_LOAD_AFFINE: return stage_tile<RCV_LOAD_AFFINE, CT, NT>(src, aux, cst, C, Himg, Wimg, n, gy0, gx0, rows_valid, cols_valid, rows, cols, fdcols, c0, dst, SD, tid);
+    case RCV_LOAD_AFFINE_RELU: return stage_tile<RCV_LOAD_AFFINE_RELU, CT, NT>(src, aux, cst, C, Himg, Wimg, n, gy0, gx0, rows_valid, cols_valid, rows, cols, fdcols, c0, dst, SD, tid);
+    case RCV_LOAD_GRAD_ENC: return stage_tile<RCV_LOAD_GRAD_ENC, CT, NT>(src, aux, cst, C, Himg, Wimg, n, gy0, gx0, rows_valid, cols_valid, rows, cols, fdcols, c0, dst, SD, tid);
+    default: return stage_tile<RCV_LOAD_GRAD_DEC, CT, NT>(src, aux, cst, C, Himg, Wimg, n, gy0, gx0, rows_valid, cols_valid, rows, cols, fdcols, c0, dst, SD, tid);
+  }
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K>
+__global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_kernel(const WgradArgs a) {
+  constexpr int NT = WAVES_M * WAVES_N * WAVES_K * 64;
+  constexpr int CBT = WM * WAVES_M * 16;
+  constexpr int CAT = WN * WAVES_N * 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* pl = smem;
+  float* gl = smem + a.pl_floats;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_k = wave % WAVES_K;
+  const int wave_n = (wave / WAVES_K) % WAVES_N;
+  const int wave_m = wave / (WAVES_K * WAVES_N);
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  const int n_ca_tiles = (a.CAP + CAT - 1) / CAT;
+  const int cb_tile = blockIdx.y / n_ca_tiles, ca_tile = blockIdx.y % n_ca_tiles;
+  const int cb0 = cb_tile * CBT, ca0 = ca_tile * CAT;
+
+  f32x4 acc[9][WM][WN];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int nn = 0; nn < WN; ++nn) acc[t][m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const int s = a.stride, d = a.dil;
+  const int ksteps = a.R * a.Wt4 / 4;
+  const int a_lane = l4 * a.SP + (wave_m * WM) * 16 + l15;
+  const int g_lane = (l4 * s) * a.SG + (wave_n * WN) * 16 + l15;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.nsplit) {
+    int t = tile;
+    const int tx_i = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int ty_i = t % a.tiles_y;
+    const int n = t / a.tiles_y;
+    const int y0 = ty_i * a.R, x0 = tx_i * a.Wt;
+    __syncthreads();
+    // P tile: R x Wt4 pixels (columns >= Wt and rows/cols outside the plane are zero)
+    const float4 bs = stage_dispatch<CBT, NT>(a.p_mode, a.p, a.p_aux, a.p_c, a.CB, a.Hp, a.Wp, n, y0, x0, a.R, a.Wt, a.R, a.Wt4,
+                                              a.fdWt4, cb0, pl, a.SP, tid);
+    bsum.x += bs.x; bsum.y += bs.y; bsum.z += bs.z; bsum.w += bs.w;
+    // G tile: IH x IW pixels around it
+    if (a.g_mode == RCV_LOAD_NCHW) {
+      const int npix = a.IH * a.IW;
+      for (int pix = tid; pix < npix; pix += NT) {
+        const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
+        const int gy = y0 * s - d + iy, gx = x0 * s - d + ix;
+        const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+#pragma unroll
+        for (int j = 0; j < CAT; ++j) {
+          float v = 0.f;
+          if (ok && j < 4 && ca0 + j < a.CA) v = a.g[((size_t)(n * a.CA + ca0 + j) * a.H + gy) * a.W + gx];
+          gl[pix * a.SG + j] = v;
+        }
+      }
+    } else {
+      stage_dispatch<CAT, NT>(a.g_mode, a.g, a.g_aux, a.g_c, a.CA, a.H, a.W, n, y0 * s - d, x0 * s - d, a.IH, a.IW, a.IH, a.IW,
+                              a.fdIW, ca0, gl, a.SG, tid);
+    }
+    __syncthreads();
+    for (int j = wave_k; j < ksteps; j += WAVES_K) {
+      const int p0 = 4 * j;
+      const int ty = fd_div(p0, a.fdWt4), tx = p0 - ty * a.Wt4;
+      float av[WM];
+#pragma unroll
+      for (int m = 0; m < WM; ++m) av[m] = pl[p0 * a.SP + a_lane + m * 16];
+      const float* gj = gl + ((ty * s) * a.IW + tx * s) * a.SG + g_lane;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float* gt = gj + ((ky * d) * a.IW + kx * d) * a.SG;
+          float bv[WN];
+#pragma unroll
+          for (int nn = 0; nn < WN; ++nn) bv[nn] = gt[nn * 16];
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn)
+              acc[ky * 3 + kx][m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[nn], acc[ky * 3 + kx][m][nn], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- reduce the WAVES_K pixel-slices of the workgroup (fixed order) ----
+  if (WAVES_K > 1) {
+    constexpr int PER_WAVE = 9 * WM * WN * 4 * 64;
+    for (int kk = 1; kk < WAVES_K; ++kk) {
+      __syncthreads();
+      float* sc = smem + (wave_m * WAVES_N + wave_n) * PER_WAVE;
+      if (wave_k == kk) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) sc[(((t * WM + m) * WN + nn) * 4 + r) * 64 + lane] = acc[t][m][nn][r];
+      }
+      __syncthreads();
+      if (wave_k == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int m = 0; m < WM; ++m)
+#pragma unroll
+            for (int nn = 0; nn < WN; ++nn)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[t][m][nn][r] += sc[(((t * WM + m) * WN + nn) * 4 + r) * 64 + lane];
+      }
+    }
+  }
+  if (wave_k == 0) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int nn = 0; nn < WN; ++nn) {
+          const int ca = ca0 + (wave_n * WN + nn) * 16 + l15;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int cb = cb0 + (wave_m * WM + m) * 16 + 4 * l4 + r;
+            if (cb < a.CBP && ca < a.CAP)
+              a.part[(((size_t)blockIdx.x * 9 + t) * a.CBP + cb) * a.CAP + ca] = acc[t][m][nn][r];
+          }
+        }
+  }
+  // ---- bias partial: sum over the threads that staged the same channel quad (fixed order) ----
+  if (a.part_bias && ca_tile == 0) {
+    constexpr int Q = CBT / 4;
+    __syncthreads();
+    float4* sb = reinterpret_cast<float4*>(smem);
+    sb[tid] = bsum;
+    __syncthreads();
+    if (tid < Q) {
+      float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int e = tid; e < NT; e += Q) { const float4 v = sb[e]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
+      const int cb = cb0 + 4 * tid;
+      if (cb < a.CBP) *reinterpret_cast<float4*>(a.part_bias + (size_t)blockIdx.x * a.CBP + cb) = u;
+    }
+  }
+}
+
+// dW[cb][ca][tap] = sum_split part[split][tap][cb][ca];  db[cb] = sum_split part_bias[split][cb]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_bias, float* __restrict__ dw,
+                                    float* __restrict__ db, int nsplit, int CB, int CA, int CBP, int CAP) {
+  const int total = 9 * CB * CA;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < total) {
+    const int ca = e % CA;
+    const int cb = (e / CA) % CB;
+    const int t = e / (CA * CB);
+    float u = 0.f;
+    const size_t stride = (size_t)9 * CBP * CAP;
+    const float* src = part + ((size_t)t * CBP + cb) * CAP + ca;
+    for (int sidx = 0; sidx < nsplit; ++sidx) u += src[sidx * stride];
+    dw[((size_t)cb * CA + ca) * 9 + t] = u;
+  } else if (db && e < total + CB) {
+    const int cb = e - total;
+    float u = 0.f;
+    for (int sidx = 0; sidx < nsplit; ++sidx) u += part_bias[(size_t)sidx * CBP + cb];
+    db[cb] = u;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+struct WTile { int WM, WN, WAVES_M, WAVES_N, WAVES_K; int cbt() const { return WM * WAVES_M * 16; } int cat() const { return WN * WAVES_N * 16; } };
+static const WTile kWT[] = {
+    {2, 2, 2, 2, 1},  // 0: 64 x 64
+    {2, 2, 2, 1, 2},  // 1: 64 x 32
+    {2, 2, 1, 2, 2},  // 2: 32 x 64
+    {2, 2, 1, 1, 4},  // 3: 32 x 32
+    {2, 1, 1, 1, 4},  // 4: 32 x 16
+    {1, 2, 1, 1, 4},  // 5: 16 x 32
+    {1, 1, 1, 1, 4},  // 6: 16 x 16
+};
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K>
+static int wlaunch_inst(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K>;
+  static size_t configured = 0;
+  if (lds > configured) {
+    RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = lds;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * WAVES_K * 64), lds, s, a);
+  RCV_HIP(hipGetLastError());
+  return RCV_OK;
+}
+
+struct WPlan { int tile; int R, Wt, Wt4, tiles_x, tiles_y, IH, IW, SP, SG, nsplit, pl_floats; size_t lds; dim3 grid; int CAP, CBP; };
+
+static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
+  const int N = op->i[RCV_I_N], H = op->i[RCV_I_H], W = op->i[RCV_I_W];
+  const int CA = op->i[RCV_I_CIN], CB = op->i[RCV_I_COUT];
+  const int Hp = op->i[RCV_I_HO], Wp = op->i[RCV_I_WO];
+  const int s = op->i[RCV_I_STRIDE], d = op->i[RCV_I_DIL];
+  RCV_CHECK_ARG(N > 0 && H > 0 && W > 0 && CA > 0 && CB > 0, "wgrad: empty shape");
+  RCV_CHECK_ARG((s == 1 || s == 2) && (d == 1 || d == 2), "wgrad: stride %d dilation %d unsupported", s, d);
+  RCV_CHECK_ARG(Hp == (H - 1) / s + 1 && Wp == (W - 1) / s + 1, "wgrad: pointwise plane %dx%d does not match %dx%d / %d", Hp, Wp, H, W, s);
+  RCV_CHECK_ARG(CB % 4 == 0, "wgrad: pointwise channels %d must be a multiple of 4", CB);
+  if (op->i[RCV_I_INMODE] == RCV_LOAD_NCHW) RCV_CHECK_ARG(CA <= 4, "wgrad: NCHW gathered operand supports <=4 channels");
+  else RCV_CHECK_ARG(CA % 4 == 0, "wgrad: gathered channels %d must be a multiple of 4", CA);
+  pl->CAP = round_up(CA, 16); pl->CBP = round_up(CB, 16);
+  const int cbt_want = pl->CBP >= 64 ? 64 : (pl->CBP >= 32 ? 32 : 16);
+  const int cat_want = pl->CAP >= 64 ? 64 : (pl->CAP >= 32 ? 32 : 16);
+  pl->tile = -1;
+  for (int t = 0; t < 7; ++t) if (kWT[t].cbt() == cbt_want && kWT[t].cat() == cat_want) pl->tile = t;
+  if (pl->tile < 0) {  // 64x16 / 16x64 combinations: fall back to the widest tile not exceeding both
+    const int cb2 = cbt_want > 32 ? 32 : cbt_want, ca2 = cat_want > 32 ? 32 : cat_want;
+    for (int t = 0; t < 7; ++t) if (kWT[t].cbt() == cb2 && kWT[t].cat() == ca2) pl->tile = t;
+  }
+  RCV_CHECK_ARG(pl->tile >= 0, "wgrad: no tile for %d x %d channels", CB, CA);
+  const WTile& wt = kWT[pl->tile];
+  pl->SP = wt.cbt() % 32 == 0 ? wt.cbt() + 16 : wt.cbt();
+  pl->SG = s == 1 ? (wt.cat() % 32 == 0 ? wt.cat() + 16 : wt.cat()) : wt.cat() + 8;
+  // pixel tile: full rows when the plane is narrow, otherwise row segments; fit a 64 KiB LDS budget
+  const size_t budget = 80 * 1024 / sizeof(float);   // two workgroups per CU
+  int Wt = Wp, nx = 1;
+  while (true) {
+    Wt = ceil_div(Wp, nx);
+    const int Wt4 = round_up(Wt, 4);
+    const size_t f = (size_t)Wt4 * pl->SP + (size_t)(2 * d + 1) * ((Wt4 - 1) * s + 2 * d + 1) * pl->SG;
+    if (f <= budget || Wt <= 4) break;
+    ++nx;
+  }
+  int R = 1;
+  const int Wt4 = round_up(Wt, 4);
+  const int IW = (Wt4 - 1) * s + 2 * d + 1;
+  while (R < Hp) {
+    const int r2 = R + 1;
+    const size_t f = (size_t)r2 * Wt4 * pl->SP + (size_t)((r2 - 1) * s + 2 * d + 1) * IW * pl->SG;
+    if (f > budget || r2 * Wt4 > 640) break;
+    R = r2;
+  }
+  R = ceil_div(Hp, ceil_div(Hp, R));
+  pl->R = R; pl->Wt = Wt; pl->Wt4 = Wt4; pl->IW = IW; pl->IH = (R - 1) * s + 2 * d + 1;
+  pl->tiles_x = ceil_div(Wp, Wt); pl->tiles_y = ceil_div(Hp, R);
+  RCV_CHECK_ARG(pl->IH * pl->IW < 65536 && R * Wt4 < 65536, "wgrad: tile too large");
+  pl->pl_floats = round_up(R * Wt4 * pl->SP, 4);
+  size_t floats = (size_t)pl->pl_floats + (size_t)pl->IH * pl->IW * pl->SG;
+  const size_t red = (size_t)wt.WAVES_M * wt.WAVES_N * 9 * wt.WM * wt.WN * 4 * 64;
+  if (wt.WAVES_K > 1 && floats < red) floats = red;
+  const size_t bias_scratch = (size_t)wt.WAVES_M * wt.WAVES_N * wt.WAVES_K * 64 * 4;
+  if (floats < bias_scratch) floats = bias_scratch;
+  pl->lds = floats * sizeof(float);
+  RCV_CHECK_ARG(pl->lds <= (size_t)h->max_lds, "wgrad: tile needs %zu B of LDS (limit %d)", pl->lds, h->max_lds);
+  const int ctiles = ceil_div(pl->CBP, wt.cbt()) * ceil_div(pl->CAP, wt.cat());
+  const int ntiles = N * pl->tiles_x * pl->tiles_y;
+  int nsplit = (2 * h->num_cus) / ctiles;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > ntiles) nsplit = ntiles;
+  pl->nsplit = nsplit;
+  pl->grid = dim3(nsplit, ctiles, 1);
+  return RCV_OK;
+}
+
+int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query) {
+  if (op->kind == RCV_OP_WGRAD_REDUCE) {
+    if (query) { query->n_part = 0; query->n_split = 0; query->part_bytes = 0; return RCV_OK; }
+    const int CA = op->i[RCV_I_CIN], CB = op->i[RCV_I_COUT], nsplit = op->i[RCV_I_NSPLIT];
+    const int CAP = round_up(CA, 16), CBP = round_up(CB, 16);
+    const float* part = (const float*)op->p[RCV_P_PART];
+    float* dw = (float*)op->p[RCV_P_OUT];
+    float* db = (float*)op->p[RCV_P_BIAS];
+    RCV_CHECK_ARG(part && dw && nsplit > 0, "wgrad_reduce: null operand");
+    const float* pb = db ? part + (size_t)nsplit * 9 * CBP * CAP : nullptr;
+    const int total = 9 * CB * CA + (db ? CB : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, part, pb, dw, db, nsplit, CB, CA, CBP, CAP);
+    RCV_HIP(hipGetLastError());
+    return RCV_OK;
+  }
+  WPlan pl;
+  int rc = wmake_plan(h, op, &pl);
+  if (rc) return rc;
+  if (query) {
+    query->n_part = 0;
+    query->n_split = pl.nsplit;
+    query->part_bytes = (size_t)pl.nsplit * (9 * (size_t)pl.CBP * pl.CAP + pl.CBP) * sizeof(float);
+    return RCV_OK;
+  }
+  WgradArgs a;
+  a.g = (const float*)op->p[RCV_P_IN]; a.g_aux = (const float*)op->p[RCV_P_IN_AUX]; a.g_c = (const float*)op->p[RCV_P_IN_C];
+  a.p = (const float*)op->p[RCV_P_IN2]; a.p_aux = (const float*)op->p[RCV_P_IN2_AUX]; a.p_c = (const float*)op->p[RCV_P_IN2_C];
+  a.part = (float*)op->p[RCV_P_PART];
+  a.g_mode = op->i[RCV_I_INMODE]; a.p_mode = op->i[RCV_I_INMODE2];
+  a.N = op->i[RCV_I_N]; a.H = op->i[RCV_I_H]; a.W = op->i[RCV_I_W]; a.Hp = op->i[RCV_I_HO]; a.Wp = op->i[RCV_I_WO];
+  a.CA = op->i[RCV_I_CIN]; a.CB = op->i[RCV_I_COUT]; a.CAP = pl.CAP; a.CBP = pl.CBP;
+  a.stride = op->i[RCV_I_STRIDE]; a.dil = op->i[RCV_I_DIL];
+  a.R = pl.R; a.Wt = pl.Wt; a.Wt4 = pl.Wt4; a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
+  a.ntiles = a.N * pl.tiles_x * pl.tiles_y; a.IH = pl.IH; a.IW = pl.IW; a.SP = pl.SP; a.SG = pl.SG;
+  a.nsplit = pl.nsplit; a.pl_floats = pl.pl_floats;
+  a.fdWt4 = make_fastdiv(pl.Wt4); a.fdIW = make_fastdiv(pl.IW);
+  RCV_CHECK_ARG(a.g && a.p && a.part, "wgrad: null operand");
+  RCV_CHECK_ARG(op->i[RCV_I_NSPLIT] == pl.nsplit, "wgrad: workspace splits %d != %d", op->i[RCV_I_NSPLIT], pl.nsplit);
+  RCV_CHECK_ARG(a.p_mode != RCV_LOAD_NCHW, "wgrad: pointwise operand cannot be NCHW");
+  RCV_CHECK_ARG(a.g_mode == RCV_LOAD_PLAIN || a.g_mode == RCV_LOAD_NCHW || a.g_c, "wgrad: gathered load mode %d needs constants", a.g_mode);
+  RCV_CHECK_ARG(a.p_mode == RCV_LOAD_PLAIN || a.p_c, "wgrad: pointwise load mode %d needs constants", a.p_mode);
+  RCV_CHECK_ARG(!(a.g_mode == RCV_LOAD_GRAD_ENC || a.g_mode == RCV_LOAD_GRAD_DEC) || a.g_aux, "wgrad: gathered gradient load needs aux");
+  RCV_CHECK_ARG(!(a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC) || a.p_aux, "wgrad: pointwise gradient load needs aux");
+  a.part_bias = (op->flags & RCV_F_BIAS) ? a.part + (size_t)pl.nsplit * 9 * pl.CBP * pl.CAP : nullptr;
+  switch (pl.tile) {
+    case 0: return wlaunch_inst<2, 2, 2, 2, 1>(a, pl.grid, pl.lds, s);
+    case 1: return wlaunch_inst<2, 2, 2, 1, 2>(a, pl.grid, pl.lds, s);
+    case 2: return wlaunch_inst<2, 2, 1, 2, 2>(a, pl.grid, pl.lds, s);
+    case 3: return wlaunch_inst<2, 2, 1, 1, 4>(a, pl.grid, pl.lds, s);
+    case 4: return wlaunch_inst<2, 1, 1, 1, 4>(a, pl.grid, pl.lds, s);
+    case 5: return wlaunch_inst<1, 2, 1, 1, 4>(a, pl.grid, pl.lds, s);
+    default: return wlaunch_inst<1, 1, 1, 1, 4>(a, pl.grid, pl.lds, s);
+  }
+}

@@ -1,0 +1,526 @@
+"""Plan/execute engine behind the nn.Module surface.
+
+A network is described once as a small graph (conv / pool / up / cls nodes, built by model.py from
+the module tree).  For every (input shape, train|eval) the engine lowers that graph to two cached
+arrays of `rcv_op` records -- one forward, one backward -- whose operands are persistent HBM
+buffers owned by the engine.  Running a pass is then ONE call into librcv.so (rcv_run), which
+enqueues every kernel of the pass on the current HIP stream: no per-layer Python, no allocation,
+no host synchronisation, graph-capturable.
+
+Data layout in HBM:
+  * activations fp32 NHWC; the image and the logits stay NCHW (reference callers' layout);
+  * per conv block only r = relu(conv+b) is stored; BatchNorm is carried as per-channel
+    (scale, shift) constants and applied by whichever kernel loads r next;
+  * parameters live in ONE flat fp32 buffer (the nn.Parameters are views into it) and their
+    gradients in a second flat buffer of the same layout -- one fused optimizer launch, one
+    contiguous all-reduce payload.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+class Value:
+    """A tensor of the graph together with how consumers must read it."""
+
+    def __init__(self, kind: str, buf: Optional[torch.Tensor], C_: int, H: int, W: int, consts=None, producer=None):
+        self.kind = kind          # 'plain' | 'affine' | 'affine_relu' | 'nchw'
+        self.buf = buf
+        self.C, self.H, self.W = C_, H, W
+        self.consts = consts      # [5][C] forward constants (scale, shift, -, -, -)
+        self.producer = producer  # _Node or None (graph input)
+        self.grad: Optional[torch.Tensor] = None       # d loss / d value, NHWC
+        self.skip_grad: Optional[torch.Tensor] = None  # extra gradient arriving through a skip connection
+        self.needs_grad = False
+        self.input_index: Optional[int] = None
+
+    @property
+    def load_mode(self) -> int:
+        return {"plain": L.LOAD_PLAIN, "affine": L.LOAD_AFFINE, "affine_relu": L.LOAD_AFFINE_RELU, "nchw": L.LOAD_NCHW}[self.kind]
+
+
+class _Node:
+    def __init__(self, d: dict, idx: int):
+        self.d = d
+        self.idx = idx
+        self.op = d["op"]
+        self.out: Optional[Value] = None
+        # per-plan tensors
+        self.t: Dict[str, torch.Tensor] = {}
+
+
+class FlatParams:
+    """All parameters in one flat fp32 device buffer; nn.Parameters become views of it."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter]):
+        self.params = list(params)
+        dev = self.params[0].device
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += _round_up(p.numel(), 4)          # 16-byte aligned slices
+        self.numel = n
+        self.data = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                sl = self.data[off:off + p.numel()].view(p.shape)
+                sl.copy_(p.data)
+                p.data = sl
+        self._sig = self.signature()
+
+    def signature(self):
+        return tuple(p.data_ptr() for p in self.params)
+
+    def intact(self) -> bool:
+        return self.signature() == self._sig
+
+    def index(self, p) -> int:
+        for k, q in enumerate(self.params):
+            if q is p:
+                return k
+        raise KeyError("parameter not registered with the engine")
+
+    def grad_view(self, k: int) -> torch.Tensor:
+        p, off = self.params[k], self.offsets[k]
+        return self.grad[off:off + p.numel()].view(p.shape)
+
+    def grad_ptr(self, p) -> int:
+        return self.grad.data_ptr() + 4 * self.offsets[self.index(p)]
+
+
+class Plan:
+    def __init__(self):
+        self.fwd: Optional[L.OpList] = None
+        self.bwd: Optional[L.OpList] = None
+        self.keep: List[object] = []          # tensors referenced by raw pointer
+        self.input_slots: List[List[tuple]] = []   # per graph input: [(oplist, op index, slot)]
+        self.dlogits_slots: List[tuple] = []
+        self.logits: Optional[torch.Tensor] = None
+        self.input_grads: List[Optional[torch.Tensor]] = []
+        self.bytes = 0
+
+
+class Engine:
+    def __init__(self, graph: dict, params: Sequence[torch.nn.Parameter], bn_modules: Sequence[torch.nn.Module]):
+        self.graph = graph
+        self.param_list = list(params)
+        self.bn_modules = list(bn_modules)
+        self.flat: Optional[FlatParams] = None
+        self.plans: Dict[tuple, Plan] = {}
+        self.device: Optional[torch.device] = None
+        self.handle = None
+
+    # ------------------------------------------------------------------ device / parameter state
+    def _ensure_device(self, dev: torch.device):
+        if dev.type != "cuda":
+            raise L.RcvError("robocupvision_amd computes on an MI355X (HIP) device only; got a tensor on '%s'. "
+                             "There is no CPU path: move the model and inputs to cuda." % dev)
+        if self.param_list[0].device != dev:
+            raise L.RcvError("model parameters are on %s but the input is on %s" % (self.param_list[0].device, dev))
+        if self.flat is None or not self.flat.intact() or self.device != dev:
+            self.device = dev
+            self.handle = L.handle(dev.index if dev.index is not None else torch.cuda.current_device())
+            self.flat = FlatParams(self.param_list)
+            self.plans.clear()
+
+    def _alloc(self, plan: Plan, *shape, dtype=torch.float32) -> torch.Tensor:
+        t = torch.empty(*shape, dtype=dtype, device=self.device)
+        plan.keep.append(t)
+        plan.bytes += t.numel() * t.element_size()
+        return t
+
+    def _zeros(self, plan: Plan, *shape, dtype=torch.float32) -> torch.Tensor:
+        t = torch.zeros(*shape, dtype=dtype, device=self.device)
+        plan.keep.append(t)
+        plan.bytes += t.numel() * t.element_size()
+        return t
+
+    def _workspace(self, plan: Plan, op: L.RcvOp) -> Optional[torch.Tensor]:
+        nbytes = L.op_workspace(self.handle, op)
+        if nbytes == 0:
+            return None
+        t = self._alloc(plan, (nbytes + 3) // 4)
+        op.p[L.RCV_P_PART] = t.data_ptr()
+        return t
+
+    # ------------------------------------------------------------------ plan construction
+    def _build(self, shapes: Sequence[tuple], training: bool) -> Plan:
+        g = self.graph
+        plan = Plan()
+        fl = self.flat
+        fwd: List[L.RcvOp] = []
+        bwd: List[L.RcvOp] = []
+        N = shapes[0][0]
+        # graph inputs
+        in_vals: List[Value] = []
+        plan.input_slots = [[] for _ in g["inputs"]]
+        for k, (spec, shp) in enumerate(zip(g["inputs"], shapes)):
+            if spec["layout"] == "nchw":
+                _, c, h, w = shp
+                v = Value("nchw", None, c, h, w)
+            else:
+                _, h, w, c = shp
+                v = Value("plain", None, c, h, w)
+                v.needs_grad = bool(spec.get("requires_grad")) and training
+            if shp[0] != N:
+                raise L.RcvError("all graph inputs must share the batch size")
+            v.input_index = k
+            in_vals.append(v)
+        nodes = [_Node(d, i) for i, d in enumerate(g["nodes"])]
+
+        def ref(r) -> Value:
+            return in_vals[r[1]] if r[0] == "in" else nodes[r[1]].out
+
+        def bind_in(op_list: List[L.RcvOp], v: Value, slot: int):
+            """Operand `slot` of the op about to be appended reads value v (patched per call for inputs)."""
+            if v.input_index is not None:
+                plan.input_slots[v.input_index].append((op_list is bwd, len(op_list), slot))
+                return 0
+            return v.buf.data_ptr()
+
+        # ---- weight packing table (all layers, one launch per forward) ----
+        jobs: List[L.RcvPackJob] = []
+
+        def add_pack(param, D0, D1, rows_from_d1, flip):
+            rows = D1 if rows_from_d1 else D0
+            cols = D0 if rows_from_d1 else D1
+            rp, cp = _round_up(rows, 4), _round_up(cols, 16)
+            dst = self._zeros(plan, 9 * rp * cp)
+            j = L.RcvPackJob()
+            j.src, j.dst, j.D0, j.D1 = param.data_ptr(), dst.data_ptr(), D0, D1
+            j.rows_from_d1, j.flip, j.rows_pad, j.cols_pad = int(rows_from_d1), int(flip), rp, cp
+            jobs.append(j)
+            return dst
+
+        bn_finalize_flags = L.F_TRAINING if training else 0
+
+        def bn_tensors(node: _Node, Cc: int):
+            node.t["consts"] = self._zeros(plan, 5, Cc)
+            node.t["mean"] = self._zeros(plan, Cc)
+            node.t["istd"] = self._zeros(plan, Cc)
+
+        pre: List[L.RcvOp] = []      # eval mode: running statistics -> constants, ahead of everything else
+
+        def emit_bn_forward(node: _Node, bn, conv_op: L.RcvOp, Cc: int, Ho: int, Wo: int):
+            """Statistics partials of conv_op -> constants (training) or running stats -> constants (eval)."""
+            if training:
+                conv_op.i[L.RCV_I_STATS] = L.STATS_FWD
+                self._workspace(plan, conv_op)
+                fwd.append(conv_op)
+                fwd.append(L.make_op(L.OP_BN_FINALIZE, bn_finalize_flags, n=N, ho=Ho, wo=Wo, cout=Cc,
+                                     npart=conv_op.i[L.RCV_I_NPART], f0=BN_MOMENTUM, f1=BN_EPS,
+                                     p_part=conv_op.p[L.RCV_P_PART], p_out=node.t["consts"].data_ptr(),
+                                     p_x0=bn.weight.data_ptr(), p_x1=bn.bias.data_ptr(),
+                                     p_x2=bn.running_mean.data_ptr(), p_x3=bn.running_var.data_ptr(),
+                                     p_x4=node.t["mean"].data_ptr(), p_x5=node.t["istd"].data_ptr()))
+            else:
+                pre.append(L.make_op(L.OP_BN_EVAL, 0, cout=Cc, f1=BN_EPS, p_out=node.t["consts"].data_ptr(),
+                                     p_x0=bn.weight.data_ptr(), p_x1=bn.bias.data_ptr(),
+                                     p_x2=bn.running_mean.data_ptr(), p_x3=bn.running_var.data_ptr()))
+                fwd.append(conv_op)
+
+        # =============================== forward ===============================
+        for node in nodes:
+            d = node.d
+            if node.op == "conv":
+                src = ref(d["src"])
+                w, b, bn = d["weight"], d.get("bias"), d["bn"]
+                Cout, Cin = w.shape[0], w.shape[1]
+                s, dil = d["stride"], d["dil"]
+                if Cin != src.C:
+                    raise L.RcvError("conv node %d: input has %d channels, weight expects %d" % (node.idx, src.C, Cin))
+                Ho, Wo = (src.H - 1) // s + 1, (src.W - 1) // s + 1
+                node.t["wp"] = add_pack(w, Cout, Cin, True, False)
+                r = self._alloc(plan, N, Ho, Wo, Cout)
+                bn_tensors(node, Cout)
+                relu_first = d.get("order", "relu_bn") == "relu_bn"
+                flags = (L.F_BIAS if b is not None else 0) | (L.F_RELU if relu_first else 0)
+                op = L.make_op(L.OP_CONV, flags, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, ho=Ho, wo=Wo, stride=s, dil=dil,
+                               inmode=src.load_mode, p_in_c=_ptr(src.consts), p_w=node.t["wp"].data_ptr(),
+                               p_bias=_ptr(b), p_out=r.data_ptr())
+                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
+                emit_bn_forward(node, bn, op, Cout, Ho, Wo)
+                node.out = Value("affine" if relu_first else "affine_relu", r, Cout, Ho, Wo, node.t["consts"], node)
+            elif node.op == "pool":
+                src = ref(d["src"])
+                if src.H % 2 or src.W % 2:
+                    raise L.RcvError("max-pool needs even spatial dims, got %dx%d" % (src.H, src.W))
+                out = self._alloc(plan, N, src.H // 2, src.W // 2, src.C)
+                op = L.make_op(L.OP_POOL_FWD, 0, n=N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
+                               p_in_c=_ptr(src.consts), p_out=out.data_ptr())
+                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
+                fwd.append(op)
+                node.out = Value("plain", out, src.C, src.H // 2, src.W // 2, None, node)
+            elif node.op == "up":
+                src = ref(d["src"])
+                w, b, bn = d["weight"], d.get("bias"), d["bn"]
+                Cin, Cout = w.shape[0], w.shape[1]
+                if Cin != src.C:
+                    raise L.RcvError("up node %d: input has %d channels, weight expects %d" % (node.idx, src.C, Cin))
+                Ho, Wo = 2 * src.H, 2 * src.W
+                node.t["wp"] = add_pack(w, Cin, Cout, False, False)
+                t = self._alloc(plan, N, Ho, Wo, Cout)
+                bn_tensors(node, Cout)
+                op = L.make_op(L.OP_TCONV, (L.F_BIAS if b is not None else 0), n=N, h=src.H, w=src.W, cin=Cin, cout=Cout,
+                               ho=Ho, wo=Wo, stride=2, dil=1, inmode=src.load_mode, p_in_c=_ptr(src.consts),
+                               p_w=node.t["wp"].data_ptr(), p_bias=_ptr(b), p_out=t.data_ptr())
+                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
+                emit_bn_forward(node, bn, op, Cout, Ho, Wo)
+                node.t["t"] = t
+                if d.get("skip") is not None:
+                    skip = ref(d["skip"])
+                    if (skip.C, skip.H, skip.W) != (Cout, Ho, Wo):
+                        raise L.RcvError("up node %d: skip tensor %s does not match output %s" %
+                                         (node.idx, (skip.C, skip.H, skip.W), (Cout, Ho, Wo)))
+                    up = self._alloc(plan, N, Ho, Wo, Cout)
+                    cop = L.make_op(L.OP_COMBINE, 0, n=N, h=Ho, w=Wo, cout=Cout, inmode2=skip.load_mode, p_in=t.data_ptr(),
+                                    p_in_c=node.t["consts"].data_ptr(), p_in2_c=_ptr(skip.consts), p_out=up.data_ptr())
+                    cop.p[L.RCV_P_IN2] = bind_in(fwd, skip, L.RCV_P_IN2) or None
+                    fwd.append(cop)
+                    node.out = Value("plain", up, Cout, Ho, Wo, None, node)
+                else:
+                    node.out = Value("affine_relu", t, Cout, Ho, Wo, node.t["consts"], node)
+            elif node.op == "cls":
+                src = ref(d["src"])
+                w, b = d["weight"], d.get("bias")
+                Cout, Cin = w.shape[0], w.shape[1]
+                if src.kind != "plain":
+                    raise L.RcvError("classifier input must be a materialised tensor")
+                if w.shape[2] != 1 or w.shape[3] != 1:
+                    raise L.RcvError("only the 1x1 classifier (classSize=1) is built; got %dx%d" % (w.shape[2], w.shape[3]))
+                logits = self._alloc(plan, N, Cout, src.H, src.W)
+                op = L.make_op(L.OP_CLS_FWD, 0, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, p_w=w.data_ptr(), p_bias=_ptr(b),
+                               p_out=logits.data_ptr())
+                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
+                fwd.append(op)
+                node.out = Value("plain", logits, Cout, src.H, src.W, None, node)
+                plan.logits = logits
+            elif node.op == "mat":
+                src = ref(d["src"])
+                out = self._alloc(plan, N, src.H, src.W, src.C)
+                op = L.make_op(L.OP_MATERIALIZE, 0, n=N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
+                               p_in_c=_ptr(src.consts), p_out=out.data_ptr())
+                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
+                fwd.append(op)
+                node.out = Value("plain", out, src.C, src.H, src.W, None, node)
+                plan.logits = out
+            else:
+                raise L.RcvError("unknown graph node '%s'" % node.op)
+
+        # =============================== backward ===============================
+        plan.input_grads = [None] * len(in_vals)
+        if training:
+            # which values need a gradient: everything produced by a node, plus flagged inputs
+            for node in nodes:
+                if node.op not in ("cls", "mat"):
+                    node.out.needs_grad = True
+
+            def grad_target(v: Value, writer_op: L.RcvOp, Ho: int, Wo: int):
+                """Configure writer_op (a dgrad-like op) to produce d loss / d v with the epilogue v's producer needs."""
+                v.grad = self._alloc(plan, N, v.H, v.W, v.C)
+                writer_op.p[L.RCV_P_OUT] = v.grad.data_ptr()
+                if v.skip_grad is not None:
+                    writer_op.flags |= L.F_RESID
+                    writer_op.p[L.RCV_P_RESID] = v.skip_grad.data_ptr()
+                prod = v.producer
+                if prod is None:
+                    plan.input_grads[v.input_index] = v.grad
+                    writer_op.i[L.RCV_I_STATS] = L.STATS_NONE
+                elif prod.op == "conv":
+                    writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_ENC
+                    writer_op.p[L.RCV_P_EPI_AUX] = v.buf.data_ptr()
+                elif prod.op == "up":
+                    writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_DEC
+                    writer_op.p[L.RCV_P_EPI_AUX] = prod.t["t"].data_ptr()
+                    writer_op.p[L.RCV_P_EPI_C] = prod.t["consts"].data_ptr()
+                else:
+                    writer_op.i[L.RCV_I_STATS] = L.STATS_NONE
+                self._workspace(plan, writer_op)
+                if prod is not None and prod.op in ("conv", "up"):
+                    prod.t["bwd_part"] = (writer_op.p[L.RCV_P_PART], writer_op.i[L.RCV_I_NPART])
+
+            def emit_bn_backward(node: _Node, bn, Cc: int, Ho: int, Wo: int):
+                part_ptr, n_part = node.t["bwd_part"]
+                node.t["bconsts"] = self._zeros(plan, 5, Cc)
+                bwd.append(L.make_op(L.OP_BN_BWD, 0, n=N, ho=Ho, wo=Wo, cout=Cc, npart=n_part, p_part=part_ptr,
+                                     p_out=node.t["bconsts"].data_ptr(), p_in_c=node.t["consts"].data_ptr(),
+                                     p_x0=bn.weight.data_ptr(), p_x1=fl.grad_ptr(bn.weight), p_x2=fl.grad_ptr(bn.bias),
+                                     p_x4=node.t["mean"].data_ptr(), p_x5=node.t["istd"].data_ptr()))
+
+            for node in reversed(nodes):
+                d = node.d
+                if node.op == "cls":
+                    src = ref(d["src"])
+                    w, b = d["weight"], d.get("bias")
+                    Cout, Cin = w.shape[0], w.shape[1]
+                    op = L.make_op(L.OP_CLS_BWD, 0, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, p_in=src.buf.data_ptr() if src.buf is not None else 0,
+                                   p_w=w.data_ptr(), p_x1=fl.grad_ptr(w), p_x2=(fl.grad_ptr(b) if b is not None else 0))
+                    if src.input_index is not None:
+                        plan.input_slots[src.input_index].append((True, len(bwd), L.RCV_P_IN))
+                    plan.dlogits_slots.append((len(bwd), L.RCV_P_IN2))
+                    grad_target(src, op, src.H, src.W)
+                    bwd.append(op)
+                elif node.op == "mat":
+                    # the gradient of the materialised output arrives from outside: copy + BN-backward sums
+                    src = ref(d["src"])
+                    op = L.make_op(L.OP_BWD_STATS, 0, n=N, h=src.H, w=src.W, cout=src.C)
+                    plan.dlogits_slots.append((len(bwd), L.RCV_P_IN))
+                    grad_target(src, op, src.H, src.W)
+                    if op.i[L.RCV_I_STATS] == L.STATS_NONE:
+                        raise L.RcvError("a materialised output must follow a conv or up block")
+                    bwd.append(op)
+                elif node.op == "up":
+                    out, src = node.out, ref(d["src"])
+                    w, b, bn = d["weight"], d.get("bias"), d["bn"]
+                    Cin, Cout = w.shape[0], w.shape[1]
+                    if out.grad is None:
+                        raise L.RcvError("up node %d has no consumer that produces its gradient" % node.idx)
+                    if d.get("skip") is not None:
+                        ref(d["skip"]).skip_grad = out.grad        # d up / d skip = identity
+                    emit_bn_backward(node, bn, Cout, out.H, out.W)
+                    # filter gradient: G = dt (2x plane), P = layer input
+                    wop = L.make_op(L.OP_WGRAD, 0, n=N, h=out.H, w=out.W, cin=Cout, ho=src.H, wo=src.W, cout=Cin, stride=2, dil=1,
+                                    inmode=L.LOAD_GRAD_DEC, inmode2=src.load_mode, p_in=out.grad.data_ptr(),
+                                    p_in_aux=node.t["t"].data_ptr(), p_in_c=node.t["bconsts"].data_ptr(),
+                                    p_in2_c=_ptr(src.consts))
+                    wop.p[L.RCV_P_IN2] = (src.buf.data_ptr() if src.buf is not None else None)
+                    if src.input_index is not None:
+                        plan.input_slots[src.input_index].append((True, len(bwd), L.RCV_P_IN2))
+                    self._workspace(plan, wop)
+                    bwd.append(wop)
+                    bwd.append(L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cout, cout=Cin, nsplit=wop.i[L.RCV_I_NSPLIT],
+                                         p_part=wop.p[L.RCV_P_PART], p_out=fl.grad_ptr(w)))
+                    if b is not None:   # bias ahead of a BatchNorm: gradient is identically zero
+                        bwd.append(L.make_op(L.OP_MEMSET, 0, count=b.numel(), p_out=fl.grad_ptr(b)))
+                    if src.needs_grad:
+                        node.t["wd"] = add_pack(w, Cin, Cout, True, False)
+                        dop = L.make_op(L.OP_CONV, 0, n=N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=2, dil=1,
+                                        inmode=L.LOAD_GRAD_DEC, p_in=out.grad.data_ptr(), p_in_aux=node.t["t"].data_ptr(),
+                                        p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
+                        grad_target(src, dop, src.H, src.W)
+                        bwd.append(dop)
+                elif node.op == "pool":
+                    out, src = node.out, ref(d["src"])
+                    if out.grad is None:
+                        raise L.RcvError("pool node %d has no gradient producer" % node.idx)
+                    if src.needs_grad:
+                        pop = L.make_op(L.OP_POOL_BWD, 0, n=N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
+                                        p_in=out.grad.data_ptr(), p_in_c=_ptr(src.consts))
+                        grad_target(src, pop, src.H, src.W)
+                        # pool backward recomputes the arg-max from the producer's r; for non-BN producers use the tensor itself
+                        pop.p[L.RCV_P_EPI_AUX] = src.buf.data_ptr() if src.buf is not None else None
+                        if src.input_index is not None:
+                            plan.input_slots[src.input_index].append((True, len(bwd), L.RCV_P_EPI_AUX))
+                        if src.producer is not None and src.producer.op == "up":
+                            raise L.RcvError("max-pool directly after a decoder block is not supported")
+                        bwd.append(pop)
+                elif node.op == "conv":
+                    out, src = node.out, ref(d["src"])
+                    w, b, bn = d["weight"], d.get("bias"), d["bn"]
+                    Cout, Cin = w.shape[0], w.shape[1]
+                    s, dil = d["stride"], d["dil"]
+                    if d.get("order", "relu_bn") != "relu_bn":
+                        raise L.RcvError("training of conv->BN->ReLU blocks is not built (inference only)")
+                    if out.grad is None:
+                        raise L.RcvError("conv node %d has no gradient producer" % node.idx)
+                    emit_bn_backward(node, bn, Cout, out.H, out.W)
+                    wop = L.make_op(L.OP_WGRAD, (L.F_BIAS if b is not None else 0), n=N, h=src.H, w=src.W, cin=Cin, ho=out.H, wo=out.W,
+                                    cout=Cout, stride=s, dil=dil, inmode=src.load_mode, inmode2=L.LOAD_GRAD_ENC,
+                                    p_in_c=_ptr(src.consts), p_in2=out.grad.data_ptr(), p_in2_aux=out.buf.data_ptr(),
+                                    p_in2_c=node.t["bconsts"].data_ptr())
+                    wop.p[L.RCV_P_IN] = (src.buf.data_ptr() if src.buf is not None else None)
+                    if src.input_index is not None:
+                        plan.input_slots[src.input_index].append((True, len(bwd), L.RCV_P_IN))
+                    self._workspace(plan, wop)
+                    bwd.append(wop)
+                    bwd.append(L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cin, cout=Cout, nsplit=wop.i[L.RCV_I_NSPLIT],
+                                         p_part=wop.p[L.RCV_P_PART], p_out=fl.grad_ptr(w),
+                                         p_bias=(fl.grad_ptr(b) if b is not None else 0)))
+                    if src.needs_grad:
+                        if s == 1:
+                            node.t["wd"] = add_pack(w, Cout, Cin, False, True)
+                            dop = L.make_op(L.OP_CONV, 0, n=N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=1, dil=dil,
+                                            inmode=L.LOAD_GRAD_ENC, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
+                                            p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
+                        else:
+                            if src.H != 2 * out.H or src.W != 2 * out.W:
+                                raise L.RcvError("stride-2 conv backward needs even input dims (got %dx%d)" % (src.H, src.W))
+                            node.t["wd"] = add_pack(w, Cout, Cin, False, False)
+                            dop = L.make_op(L.OP_TCONV, 0, n=N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=2, dil=1,
+                                            inmode=L.LOAD_GRAD_ENC, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
+                                            p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
+                        grad_target(src, dop, src.H, src.W)
+                        bwd.append(dop)
+
+        # ---- the pack launch goes first in the forward list ----
+        table = (L.RcvPackJob * len(jobs))(*jobs)
+        nbytes = C.sizeof(table)
+        host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
+        dev_table = host.to(self.device)
+        plan.keep.append(dev_table)
+        max_elems = max(9 * j.rows_pad * j.cols_pad for j in jobs)
+        pack_op = L.make_op(L.OP_PACK, 0, count=len(jobs), aux0=max_elems, p_in=dev_table.data_ptr())
+        head = [pack_op] + pre
+        for slots in plan.input_slots:
+            for i, (is_bwd, k, sl) in enumerate(slots):
+                if not is_bwd:
+                    slots[i] = (is_bwd, k + len(head), sl)
+        fwd = head + fwd
+        plan.fwd = L.OpList(fwd)
+        plan.bwd = L.OpList(bwd)
+        assert nbytes == dev_table.numel()
+        return plan
+
+    # ------------------------------------------------------------------ execution
+    def _plan_for(self, inputs: Sequence[torch.Tensor], training: bool) -> Plan:
+        self._ensure_device(inputs[0].device)
+        key = (tuple(tuple(t.shape) for t in inputs), training)
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = self._build([tuple(t.shape) for t in inputs], training)
+            self.plans[key] = plan
+        return plan
+
+    def forward(self, inputs: Sequence[torch.Tensor], training: bool) -> torch.Tensor:
+        for t in inputs:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise L.RcvError("engine inputs must be contiguous float32 tensors")
+        plan = self._plan_for(inputs, training)
+        for k, t in enumerate(inputs):
+            for (is_bwd, idx, slot) in plan.input_slots[k]:
+                (plan.bwd if is_bwd else plan.fwd).arr[idx].p[slot] = t.data_ptr()
+        plan.fwd.run(self.handle, torch.cuda.current_stream(self.device).cuda_stream)
+        if training:
+            nbt = [m.num_batches_tracked for m in self.bn_modules if m.num_batches_tracked is not None]
+            if nbt:
+                torch._foreach_add_(nbt, 1)
+        self._last = (plan, [t for t in inputs])
+        return plan.logits
+
+    def backward(self, dlogits: torch.Tensor):
+        plan, _inputs = self._last
+        if plan.bwd is None or plan.bwd.n == 0:
+            raise L.RcvError("backward called on an eval-mode forward; call model.train() first")
+        if dlogits.dtype != torch.float32 or not dlogits.is_contiguous() or dlogits.shape != plan.logits.shape:
+            dlogits = dlogits.to(torch.float32).contiguous()
+        for (idx, slot) in plan.dlogits_slots:
+            plan.bwd.arr[idx].p[slot] = dlogits.data_ptr()
+        plan.bwd.run(self.handle, torch.cuda.current_stream(self.device).cuda_stream)
+        return plan

@@ -1,0 +1,467 @@
+"""Drop-in counterpart of the reference's ``model`` module for the ROBO-UNet / U-Net hot path.
+
+Same public names, constructor arguments, sub-module names, ``state_dict`` keys and parameter
+order as the reference (model.py:76-124, 166-199, 379-414, 461-567), so a caller written against
+``from model import *`` (train.py:3,13; test.py:14; detect.py:13) keeps working -- but ``forward``
+and ``backward`` run as hand-written HIP kernels on gfx950 through librcv.so (see engine.py).
+
+The ``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.ConvTranspose2d`` children exist only as parameter
+containers (identical construction order => identical random init for a given seed, identical
+state_dict); their own ``forward`` is never used.  There is no CPU path: calling a module on a
+CPU tensor raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import Engine
+
+__all__ = ["ROBO_UNet", "CrossEntropyLoss2d", "DiceLoss", "PB_FCN", "PB_FCN_2", "LabelProp", "Conv", "Pool", "LevelDown",
+           "upSampleTransposeConv", "UltClassifier", "ConvPoolSimple", "pruneModelNew", "count_zero_weights", "getParamSize"]
+
+
+# ------------------------------------------------------------------------------------------
+# autograd glue: one node for the whole network
+# ------------------------------------------------------------------------------------------
+class _EngineFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine: Engine, training: bool, n_inputs: int, *tensors):
+        inputs = [t.detach() for t in tensors[:n_inputs]]
+        out = engine.forward(inputs, training)
+        ctx.engine = engine
+        ctx.n_inputs = n_inputs
+        ctx.n_params = len(tensors) - n_inputs
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        eng = ctx.engine
+        fl = eng.flat
+        # a parameter whose .grad already aliases the engine's gradient buffer is about to be
+        # overwritten: detach it first so autograd's accumulation keeps its meaning
+        base, end = fl.grad.data_ptr(), fl.grad.data_ptr() + 4 * fl.numel
+        for p in fl.params:
+            if p.grad is not None and base <= p.grad.data_ptr() < end:
+                p.grad = p.grad.clone()
+        plan = eng.backward(grad_out)
+        in_grads = []
+        for k in range(ctx.n_inputs):
+            g = plan.input_grads[k] if ctx.needs_input_grad[3 + k] else None
+            in_grads.append(g)
+        p_grads = [fl.grad_view(k) for k in range(ctx.n_params)]
+        return (None, None, None, *in_grads, *p_grads)
+
+
+def _run_engine(engine: Engine, training: bool, inputs: List[torch.Tensor]) -> torch.Tensor:
+    return _EngineFunction.apply(engine, training, len(inputs), *inputs, *engine.param_list)
+
+
+def _bn_modules(m: nn.Module):
+    return [x for x in m.modules() if isinstance(x, nn.BatchNorm2d)]
+
+
+class _BlockMixin:
+    """Standalone call of a single block (NCHW in, NCHW out like the reference's blocks): the block
+    becomes a one-node graph with an NHWC input and a materialised output."""
+
+    def _block_graph(self):
+        raise NotImplementedError
+
+    def _block_forward(self, *xs: torch.Tensor) -> torch.Tensor:
+        eng = self.__dict__.get("_engine")
+        if eng is None:
+            graph = self._block_graph()
+            eng = Engine(graph, list(self.parameters()), _bn_modules(self))
+            self.__dict__["_engine"] = eng
+        ins = [x.permute(0, 2, 3, 1).contiguous() for x in xs]
+        y = _run_engine(eng, self.training, ins)
+        return y.permute(0, 3, 1, 2)
+
+
+# ------------------------------------------------------------------------------------------
+# building blocks (reference: model.py:92-124, 166-199, 379-414)
+# ------------------------------------------------------------------------------------------
+class Pool(nn.Module):
+    """MaxPool2d(2,2) (model.py:92-103).  Parameter-free; inside a network it is fused with the
+    producer's BatchNorm apply."""
+
+    def __init__(self, ch, stride=2):
+        super().__init__()
+        if stride != 2:
+            raise NotImplementedError("only the 2x2/2 max-pool of the reference networks is built")
+        self.ch = ch
+        self.stride = stride
+        self.pool = nn.MaxPool2d(stride, stride)     # container for repr/state parity only
+
+    def forward(self, x):
+        raise L.RcvError("Pool is executed as part of its network graph (ROBO_UNet(pool=True)); standalone use is not built")
+
+    def getComp(self, W, H, pruned):
+        return W * H * self.ch, W // self.stride, H // self.stride
+
+
+class Conv(nn.Module, _BlockMixin):
+    """bn(relu(conv3x3(x))) -- ReLU before BatchNorm (model.py:105-124)."""
+
+    def __init__(self, inplanes, planes, size, stride=1):
+        super().__init__()
+        if size != 3:
+            raise NotImplementedError("only 3x3 Conv blocks are built (reference networks use size=3)")
+        self.stride = stride
+        self.size = size
+        self.inch = inplanes
+        self.ch = planes
+        self.conv = nn.Conv2d(inplanes, planes, kernel_size=size, padding=size // 2, stride=stride)
+        self.bn = nn.BatchNorm2d(planes)
+
+    def _node(self, src):
+        return {"op": "conv", "src": src, "weight": self.conv.weight, "bias": self.conv.bias, "bn": self.bn,
+                "stride": self.stride, "dil": 1, "order": "relu_bn"}
+
+    def _block_graph(self):
+        return {"inputs": [{"layout": "nhwc", "requires_grad": True}],
+                "nodes": [self._node(("in", 0)), {"op": "mat", "src": ("node", 0)}]}
+
+    def forward(self, x):
+        return self._block_forward(x)
+
+    def getComp(self, W, H, pruned):
+        W = W // self.stride
+        H = H // self.stride
+        ratio = float(self.conv.weight.nonzero().size(0)) / float(self.conv.weight.numel()) if pruned else 1
+        return self.size * self.size * W * H * self.inch * self.ch * 2 * ratio + W * H * self.ch * 4, W, H
+
+
+class ConvPoolSimple(nn.Module, _BlockMixin):
+    """relu(bn(conv(x))) with dilation, no bias (model.py:166-176); inference only here."""
+
+    def __init__(self, inplanes, planes, size, stride, padding, dilation, bias, *_ignored):
+        super().__init__()
+        if size != 3 or padding != dilation:
+            raise NotImplementedError("ConvPoolSimple is built for 3x3 kernels with padding == dilation")
+        self.stride, self.dilation = stride, dilation
+        self.conv = nn.Conv2d(inplanes, planes, size, stride=stride, padding=padding, dilation=dilation, bias=bias)
+        self.bn = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU()
+
+    def _node(self, src):
+        return {"op": "conv", "src": src, "weight": self.conv.weight, "bias": self.conv.bias, "bn": self.bn,
+                "stride": self.stride, "dil": self.dilation, "order": "bn_relu"}
+
+    def _block_graph(self):
+        return {"inputs": [{"layout": "nhwc", "requires_grad": False}],
+                "nodes": [self._node(("in", 0)), {"op": "mat", "src": ("node", 0)}]}
+
+    def forward(self, x):
+        if self.training:
+            raise L.RcvError("ConvPoolSimple (conv->BN->ReLU) is built for inference only; call .eval()")
+        return self._block_forward(x)
+
+
+class upSampleTransposeConv(nn.Module, _BlockMixin):
+    """relu(bn(ConvTranspose2d(k3,s2,p1,op1)(x))) (model.py:178-199)."""
+
+    def __init__(self, inplanes, planes):
+        super().__init__()
+        self.stride = 2
+        self.size = 3
+        self.inch = inplanes
+        self.ch = planes
+        self.relu = nn.ReLU()
+        self.conv = nn.ConvTranspose2d(inplanes, planes, kernel_size=3, padding=1, stride=2, output_padding=1, bias=True)
+        self.bn = nn.BatchNorm2d(planes)
+
+    def _node(self, src, skip):
+        return {"op": "up", "src": src, "skip": skip, "weight": self.conv.weight, "bias": self.conv.bias, "bn": self.bn}
+
+    def _block_graph(self):
+        return {"inputs": [{"layout": "nhwc", "requires_grad": True}],
+                "nodes": [self._node(("in", 0), None), {"op": "mat", "src": ("node", 0)}]}
+
+    def forward(self, x):
+        return self._block_forward(x)
+
+    def getComp(self, W, H, pruned):
+        ratio = float(self.conv.weight.nonzero().size(0)) / float(self.conv.weight.numel()) if pruned else 1
+        return self.size * self.size * W * H * self.inch * self.ch * 2 * ratio + W * H * self.ch * 4, W * self.stride, H * self.stride
+
+
+class LevelDown(nn.Module):
+    """One encoder level (model.py:379-401): [Pool], Conv0 (stride 2 when downsampling without
+    pooling), Conv1.. ; children are named exactly like the reference (state_dict keys)."""
+
+    def __init__(self, inplanes, planes, levels, doPool, pool=False):
+        super().__init__()
+        self.layers = nn.Sequential()
+        first_stride = 1
+        if pool:
+            if doPool:
+                self.layers.add_module("Pool", Pool(inplanes, 2))
+                levels -= 1
+        elif doPool:
+            first_stride = 2
+        self.layers.add_module("Conv0", Conv(inplanes, planes, 3, stride=first_stride))
+        for i in range(levels - 1):
+            self.layers.add_module("Conv%d" % (i + 1), Conv(planes, planes, 3))
+
+    def _nodes(self, nodes: list, src):
+        """Append this level's nodes; returns the reference of its output."""
+        for m in self.layers:
+            if isinstance(m, Pool):
+                nodes.append({"op": "pool", "src": src})
+            else:
+                nodes.append(m._node(src))
+            src = ("node", len(nodes) - 1)
+        return src
+
+    def forward(self, x):
+        for m in self.layers:
+            x = m(x)
+        return x
+
+
+class UltClassifier(nn.Module):
+    """1x1 classifier (model.py:403-414); the pooled/dropout variant belongs to the patch
+    classification scripts and is out of scope."""
+
+    def __init__(self, inplanes, nClass, pool, dropout=0.5, size=1):
+        super().__init__()
+        if pool:
+            raise NotImplementedError("UltClassifier(pool=True) (patch classification) is outside the segmentation hot path")
+        self.layers = nn.Sequential()
+        self.layers.add_module("Class", nn.Conv2d(inplanes, nClass, size, padding=size // 2))
+
+    def _node(self, src):
+        c = self.layers.Class
+        return {"op": "cls", "src": src, "weight": c.weight, "bias": c.bias}
+
+    def forward(self, x):
+        raise L.RcvError("UltClassifier is executed as part of its network graph; standalone use is not built")
+
+
+# ------------------------------------------------------------------------------------------
+# ROBO_UNet (model.py:461-536)
+# ------------------------------------------------------------------------------------------
+class ROBO_UNet(nn.Module):
+    def __init__(self, noScale=False, planes=8, nClass=5, depth=4, levels=2, bellySize=5, bellyPlanes=128, pool=False, v2=False,
+                 classSize=1):
+        super().__init__()
+        if v2:
+            raise NotImplementedError("the v2 variant (concatenated skips, 3x3 classifier) is a later row of the scope table")
+        self.numClass = nClass
+        self.planes = planes
+        self.v2 = v2
+        self.img_shape = (240, 320) if noScale else (120, 160)
+        if noScale:
+            depth += 1
+        maxDepth = planes * pow(2, depth - 1)
+
+        self.downPart = nn.ModuleList()
+        self.downPart.add_module("Level0", LevelDown(3, planes, levels - 1, False, pool))
+        for i in range(depth - 1):
+            nCh = planes * pow(2, i)
+            self.downPart.add_module("Level%d" % (i + 1), LevelDown(nCh, nCh * 2, levels, True, pool))
+
+        self.PB = nn.Sequential()
+        if bellySize > 0:
+            self.PB.add_module("PB_1", LevelDown(maxDepth, bellyPlanes, bellySize - 1, False))
+            self.PB.add_module("PB_2", LevelDown(bellyPlanes, maxDepth, 1, False))
+
+        self.upPart = nn.ModuleList()
+        for i in range(depth - 1):
+            nCh = planes * pow(2, depth - 1 - i)
+            self.upPart.add_module("Up%d" % i, upSampleTransposeConv(nCh, nCh // 2))
+
+        self.segmenter = UltClassifier(planes, nClass, False, size=classSize)
+
+    # graph of model.py:495-511
+    def _graph(self):
+        nodes: list = []
+        downs = [("in", 0)]
+        for level in self.downPart:
+            downs.append(level._nodes(nodes, downs[-1]))
+        for level in self.PB:
+            downs[-1] = level._nodes(nodes, downs[-1])
+        up = downs[-1]
+        for i, layer in enumerate(self.upPart):
+            nodes.append(layer._node(up, downs[-(i + 2)]))
+            up = ("node", len(nodes) - 1)
+        nodes.append(self.segmenter._node(up))
+        return {"inputs": [{"layout": "nchw"}], "nodes": nodes}
+
+    def _get_engine(self) -> Engine:
+        eng = self.__dict__.get("_engine")
+        if eng is None:
+            eng = Engine(self._graph(), list(self.parameters()), _bn_modules(self))
+            self.__dict__["_engine"] = eng
+        return eng
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("ROBO_UNet expects float32 [B,3,H,W], got %s" % (tuple(x.shape),))
+        down = 2 ** (len(self.downPart) - 1)
+        if x.shape[2] % down or x.shape[3] % down:
+            raise ValueError("H and W must be multiples of %d (got %dx%d)" % (down, x.shape[2], x.shape[3]))
+        x = x.to(torch.float32).contiguous()
+        return _run_engine(self._get_engine(), self.training, [x])
+
+    def get_computations(self, pruned=False):
+        """Analytic per-layer operation counts (model.py:513-536); host arithmetic only."""
+        H, W = self.img_shape
+        computations = []
+        for part in self.downPart:
+            for module in part.layers:
+                comp, W, H = module.getComp(W, H, pruned)
+                computations.append(comp)
+        for part in self.PB:
+            for module in part.layers:
+                comp, W, H = module.getComp(W, H, pruned)
+                computations.append(comp)
+        for module in self.upPart:
+            comp, W, H = module.getComp(W, H, pruned)
+            computations.append(comp)
+        computations.append(self.img_shape[0] * self.img_shape[1] * self.numClass * self.planes * 2)
+        return computations
+
+
+# ------------------------------------------------------------------------------------------
+# CrossEntropyLoss2d (model.py:76-82) + fused arg-max / accuracy (train.py:70-71)
+# ------------------------------------------------------------------------------------------
+class _CEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, weight, module):
+        if logits.device.type != "cuda":
+            raise L.RcvError("CrossEntropyLoss2d runs on the HIP device only (got %s)" % logits.device)
+        h = L.handle(logits.device.index if logits.device.index is not None else torch.cuda.current_device())
+        logits_c = logits.detach().to(torch.float32).contiguous()
+        targets_c = targets.detach().to(torch.int64).contiguous()
+        N, Cc, H, W = logits_c.shape
+        if targets_c.shape != (N, H, W):
+            raise ValueError("targets must be [B,H,W] matching logits %s, got %s" % (tuple(logits_c.shape), tuple(targets_c.shape)))
+        out = torch.empty(4, dtype=torch.float32, device=logits.device)
+        argmax = torch.empty(N, H, W, dtype=torch.uint8, device=logits.device)
+        op = L.make_op(L.OP_CE_FWD, L.F_ARGMAX, n=N, h=H, w=W, cout=Cc, p_in=logits_c.data_ptr(), p_in2=targets_c.data_ptr(),
+                       p_w=(weight.data_ptr() if weight is not None else 0), p_out=out.data_ptr(), p_x0=argmax.data_ptr())
+        nbytes = L.op_workspace(h, op)
+        part = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=logits.device)
+        op.p[L.RCV_P_PART] = part.data_ptr()
+        L.OpList([op]).run(h, torch.cuda.current_stream(logits.device).cuda_stream)
+        ctx.save_for_backward(logits_c, targets_c, out)
+        ctx.weight = weight
+        ctx.handle = h
+        module.last_argmax = argmax
+        module.last_stats = out          # [loss, sum_w, #correct, sum_w*nll]
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        logits, targets, out = ctx.saved_tensors
+        N, Cc, H, W = logits.shape
+        go = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        dl = torch.empty_like(logits)
+        w = ctx.weight
+        op = L.make_op(L.OP_CE_BWD, 0, n=N, h=H, w=W, cout=Cc, p_in=logits.data_ptr(), p_in2=targets.data_ptr(),
+                       p_w=(w.data_ptr() if w is not None else 0), p_x0=out.data_ptr(), p_x1=go.data_ptr(), p_out=dl.data_ptr())
+        L.OpList([op]).run(ctx.handle, torch.cuda.current_stream(logits.device).cuda_stream)
+        return dl, None, None, None
+
+
+class CrossEntropyLoss2d(nn.Module):
+    """NLLLoss(weight, mean)(log_softmax(inputs, 1), targets) (model.py:76-82).  After a call,
+    ``last_argmax`` (uint8 [B,H,W], first maximum on ties) and ``last_stats[2]`` (#pixels whose
+    arg-max equals the target) hold what train.py:70-71 computes with torch.max."""
+
+    def __init__(self, weight=None):
+        super().__init__()
+        self.register_buffer("weight", None if weight is None else torch.as_tensor(weight, dtype=torch.float32).clone())
+        self.last_argmax: Optional[torch.Tensor] = None
+        self.last_stats: Optional[torch.Tensor] = None
+
+    def forward(self, inputs, targets):
+        w = self.weight
+        if w is not None and w.device != inputs.device:
+            w = w.to(inputs.device)
+            self.weight = w
+        return _CEFunction.apply(inputs, targets, w, self)
+
+
+# ------------------------------------------------------------------------------------------
+# LabelProp (model.py:538-567), inference only
+# ------------------------------------------------------------------------------------------
+class LabelProp(nn.Module):
+    def __init__(self, numClass, numPlanes, dropout=0.0):
+        super().__init__()
+        self.pre = ConvPoolSimple(8, numPlanes // 4, 3, 1, 1, 1, False, dropout)
+        self.down1 = ConvPoolSimple(numPlanes // 4, numPlanes // 2, 3, 2, 1, 1, False, dropout)
+        self.down2 = ConvPoolSimple(numPlanes // 2, numPlanes // 2, 3, 2, 1, 1, False, dropout)
+        self.down3 = ConvPoolSimple(numPlanes // 2, numPlanes, 3, 2, 1, 1, False, dropout)
+        self.conv1 = ConvPoolSimple(numPlanes, numPlanes * 2, 3, 1, 2, 2, False, dropout)
+        self.conv2 = ConvPoolSimple(numPlanes * 2, numPlanes * 2, 3, 1, 2, 2, False, dropout)
+        self.conv3 = ConvPoolSimple(numPlanes * 2, numPlanes, 3, 1, 2, 2, False, dropout)
+        self.upConv1 = upSampleTransposeConv(numPlanes, numPlanes // 2)
+        self.upConv2 = upSampleTransposeConv(numPlanes // 2, numPlanes // 2)
+        self.upConv3 = upSampleTransposeConv(numPlanes // 2, numPlanes // 2)
+        self.classifier = nn.Conv2d(numPlanes // 2, numClass, 1, padding=0)
+
+    def forward(self, x):
+        raise L.RcvError("LabelProp inference is a later row of the scope table (not built yet)")
+
+
+# ------------------------------------------------------------------------------------------
+# host-side helpers of the module surface (model.py:45-74) -- scalar bookkeeping, not hot path
+# ------------------------------------------------------------------------------------------
+def pruneModelNew(params, ratio=0.01):
+    """Magnitude pruning masks (model.py:45-57): zero weights below ratio*max|w|, return the masks."""
+    indices = []
+    for param in params:
+        if param.dim() > 1:
+            with torch.no_grad():
+                thresh = torch.max(torch.abs(param)) * ratio
+                mask = torch.abs(param) < thresh
+                print("Pruned %f%% of the weights" % (float(torch.sum(mask)) / float(torch.sum(param != 0)) * 100))
+                param[mask] = 0
+                indices.append(torch.abs(param) < thresh)
+    return indices
+
+
+def count_zero_weights(model):
+    """Fraction of weights below 1% of their tensor's maximum (model.py:59-66)."""
+    small = 0.0
+    total = 0
+    for param in model.parameters():
+        mx = torch.max(torch.abs(param))
+        small += float((torch.abs(param) < mx * 0.01).sum())
+        total += param.numel()
+    return float(small / total)
+
+
+def getParamSize(x):
+    n = 1
+    for s in x.size():
+        n *= s
+    return n
+
+
+class _OutOfScope(nn.Module):
+    _what = ""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("%s belongs to the older PB-FCN generation of the reference (trainer.py/tester.py) and is "
+                                  "outside the ROBO-UNet hot path this package implements (SURVEY.md section 8f)" % self._what)
+
+
+class PB_FCN(_OutOfScope):
+    _what = "PB_FCN"
+
+
+class PB_FCN_2(_OutOfScope):
+    _what = "PB_FCN_2"
+
+
+class DiceLoss(_OutOfScope):
+    _what = "DiceLoss (--useDice)"

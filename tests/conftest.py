@@ -1,0 +1,51 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # GPU tests are skipped (not failed) when collected on a machine without a device and no -m filter
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def layer_kats():
+    return np.load(os.path.join(GOLDEN, "layer_kats.npz"))
+
+
+@pytest.fixture(scope="session")
+def net_kats():
+    return np.load(os.path.join(GOLDEN, "whole_net.npz"))
+
+
+@pytest.fixture(scope="session")
+def net_meta():
+    with open(os.path.join(GOLDEN, "whole_net.json")) as f:
+        return json.load(f)
+
+
+def sd_hash(sd):
+    import hashlib
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()[:16]

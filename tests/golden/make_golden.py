@@ -1,0 +1,273 @@
+"""Golden-vector generator.  Runs ONLY in the build container, where /root/reference exists.
+
+It imports the reference's ``model.py`` (pure PyTorch), runs it on seeded inputs
+on the CPU with 8 threads and stores inputs / expected outputs as small ``.npz`` / ``.json``
+fixtures next to this script.  Nothing from the reference's source text is stored: fixtures
+are tensors (inputs, parameters produced by the reference constructors, outputs, gradients).
+
+    python tests/golden/make_golden.py            # regenerate everything
+
+The pattern follows the reference's own known-answer dumper (testDumper.py:21-75) but with
+seeded inputs and train-mode / backward coverage.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+THREADS = 8
+
+
+def sd_hash(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()[:16]
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()      # copy: later in-place updates must not leak into a fixture
+
+
+def block_kat(ref, out, name, mod, x, seed):
+    """One reference block: train-mode fwd + bwd, running stats, then eval-mode fwd."""
+    g = torch.Generator().manual_seed(seed)
+    # non-trivial BN affine so gamma/beta gradients and folding are exercised
+    for m in mod.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.2)
+    for k, v in mod.state_dict().items():
+        out["%s/p/%s" % (name, k)] = npy(v)
+    x = x.clone().requires_grad_(True)
+    mod.train()
+    y = mod(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out[name + "/x"] = npy(x)
+    out[name + "/gy"] = npy(gy)
+    out[name + "/y_train"] = npy(y)
+    out[name + "/gx"] = npy(x.grad)
+    for k, p in mod.named_parameters():
+        out["%s/g/%s" % (name, k)] = npy(p.grad)
+    for k, v in mod.state_dict().items():
+        if "running" in k:
+            out["%s/after/%s" % (name, k)] = npy(v)
+    mod.eval()
+    with torch.no_grad():
+        out[name + "/y_eval"] = npy(mod(x))
+
+
+def layer_kats(ref):
+    out = {}
+    g = torch.Generator().manual_seed(2024)
+    torch.manual_seed(7)
+    cases = [("conv_3_8_s1", 3, 8, 1, (2, 12, 16)), ("conv_8_16_s2", 8, 16, 2, (2, 12, 16)),
+             ("conv_16_16_s1", 16, 16, 1, (2, 12, 16)), ("conv_32_64_s2", 32, 64, 2, (2, 8, 12)),
+             ("conv_64_64_s1", 64, 64, 1, (2, 6, 10)), ("conv_128_128_s1", 128, 128, 1, (3, 5, 7)),
+             ("conv_8_8_s1_odd", 8, 8, 1, (1, 7, 9))]
+    for i, (name, cin, cout, s, (n, h, w)) in enumerate(cases):
+        block_kat(ref, out, name, ref.Conv(cin, cout, 3, s), torch.randn(n, cin, h, w, generator=g), 100 + i)
+    ups = [("up_16_8", 16, 8, (2, 6, 8)), ("up_64_32", 64, 32, (2, 4, 6)), ("up_128_64", 128, 64, (1, 3, 5))]
+    for i, (name, cin, cout, (n, h, w)) in enumerate(ups):
+        block_kat(ref, out, name, ref.upSampleTransposeConv(cin, cout), torch.randn(n, cin, h, w, generator=g), 200 + i)
+    # dilated conv->BN->ReLU blocks used by LabelProp (ConvPoolSimple, model.py:166-176)
+    cps = [("cps_32_64_d2", 32, 64, 1, 2, 2, (2, 9, 11)), ("cps_8_16_s2", 8, 16, 2, 1, 1, (2, 12, 16))]
+    for i, (name, cin, cout, s, p, d, (n, h, w)) in enumerate(cps):
+        block_kat(ref, out, name, ref.ConvPoolSimple(cin, cout, 3, s, p, d, False),
+                  torch.randn(n, cin, h, w, generator=g), 300 + i)
+    # max-pool (model.py:92-100)
+    x = torch.randn(2, 8, 12, 16, generator=g, requires_grad=True)
+    y = ref.Pool(8, 2)(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out.update({"pool/x": npy(x), "pool/y": npy(y), "pool/gy": npy(gy), "pool/gx": npy(x.grad)})
+    # classifier (model.py:403-414)
+    cl = ref.UltClassifier(8, 5, False, size=1)
+    x = torch.randn(2, 8, 12, 16, generator=g, requires_grad=True)
+    y = cl(x)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    out.update({"cls/x": npy(x), "cls/y": npy(y), "cls/gy": npy(gy), "cls/gx": npy(x.grad)})
+    for k, p in cl.named_parameters():
+        out["cls/p/" + k] = npy(p)
+        out["cls/g/" + k] = npy(p.grad)
+    # CrossEntropyLoss2d (model.py:76-82) with the train.py:309 weights, + argmax (train.py:70)
+    for name, wts in (("ce_w", [1, 10, 30, 10, 2]), ("ce_now", None)):
+        crit = ref.CrossEntropyLoss2d(None if wts is None else torch.tensor(wts, dtype=torch.float32))
+        lg = (torch.randn(2, 5, 12, 16, generator=g) * 3).requires_grad_(True)
+        t = torch.randint(0, 5, (2, 12, 16), generator=g)
+        loss = crit(lg, t)
+        loss.backward()
+        out.update({name + "/logits": npy(lg), name + "/t": npy(t), name + "/loss": npy(loss),
+                    name + "/glogits": npy(lg.grad), name + "/argmax": npy(torch.max(lg, 1)[1])})
+        if wts is not None:
+            out[name + "/w"] = np.asarray(wts, dtype=np.float32)
+    # argmax tie rule (first max wins)
+    tie = torch.tensor([1.0, 3.0, 3.0, 2.0]).view(1, 4, 1, 1)
+    out["tie/argmax"] = npy(torch.max(tie, 1)[1])
+    np.savez_compressed(os.path.join(HERE, "layer_kats.npz"), **out)
+    print("layer_kats.npz: %d arrays" % len(out))
+
+
+def grad_summary(model):
+    rows = {}
+    for k, p in model.named_parameters():
+        gr = p.grad.double()
+        rows[k] = [float(gr.sum()), float(gr.abs().sum()), float(gr.norm())]
+    return rows
+
+
+def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta):
+    """The train.py:43-74 step on the reference, seeds as SURVEY.md 8(c)."""
+    torch.manual_seed(12345678)
+    model = ref.ROBO_UNet(**ctor_kwargs)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 3, H, W, generator=g)
+    t = torch.randint(0, 5, (B, H, W), generator=g)
+    crit = ref.CrossEntropyLoss2d(torch.tensor([1, 10, 30, 10, 2], dtype=torch.float32))
+    decay, lr, transfer = 1e-6, 1e-3, 0
+    opt = torch.optim.Adam([
+        {'params': model.downPart[0:transfer].parameters(), 'lr': lr * 10},
+        {'params': model.downPart[transfer:].parameters()},
+        {'params': model.PB.parameters()},
+        {'params': model.upPart.parameters()},
+        {'params': model.segmenter.parameters()}], lr=lr)
+    model.train()
+    opt.zero_grad()
+    pred = model(x)
+    ce = crit(pred, t)
+    reg = 0
+    for p in model.parameters():
+        reg = reg + torch.sum(torch.abs(p))
+    reg = decay * reg
+    loss = ce + reg
+    loss.backward()
+    gsum = grad_summary(model)
+    gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())))
+    opt.step()
+    _, pc = torch.max(pred, 1)
+    top2 = torch.topk(pred.detach(), 2, dim=1)[0]
+    margin = (top2[:, 0] - top2[:, 1])
+    sd1 = model.state_dict()
+    model.eval()
+    with torch.no_grad():
+        pred_eval = model(x)
+    m = {
+        "ctor": ctor_kwargs, "B": B, "H": H, "W": W, "threads": torch.get_num_threads(),
+        "torch": torch.__version__, "sd_hash_init": sd_hash(sd0), "sd_hash_after_step": sd_hash(sd1),
+        "n_params": int(sum(p.numel() for p in model.parameters())),
+        "sum_p": float(sum(v.double().sum() for k, v in sd0.items() if v.dtype.is_floating_point and "running" not in k)),
+        "logits_sum": float(pred.double().sum()), "logits_abs_sum": float(pred.double().abs().sum()),
+        "ce": float(ce), "reg": float(reg), "loss": float(loss), "grad_norm": gnorm,
+        "argmax_hist": [int((pc == c).sum()) for c in range(5)], "correct": int((pc == t).sum()),
+        "n_margin_lt_1e-4": int((margin < 1e-4).sum()), "n_margin_lt_1e-5": int((margin < 1e-5).sum()),
+        "min_margin": float(margin.min()),
+        "bn0_running_mean": [float(v) for v in sd1["downPart.Level0.layers.Conv0.bn.running_mean"]],
+        "bn0_running_var": [float(v) for v in sd1["downPart.Level0.layers.Conv0.bn.running_var"]],
+        "eval_logits_sum": float(pred_eval.double().sum()),
+        "eval_argmax_hist": [int((torch.max(pred_eval, 1)[1] == c).sum()) for c in range(5)],
+        "grad_summary": gsum,
+        "param_after_step_sum": {k: float(v.double().sum()) for k, v in sd1.items() if v.dtype.is_floating_point},
+    }
+    meta[tag] = m
+    out_npz[tag + "/argmax"] = npy(pc).astype(np.uint8)
+    out_npz[tag + "/eval_argmax"] = npy(torch.max(pred_eval, 1)[1]).astype(np.uint8)
+    # flat indices of near-tie pixels (top-2 logit margin < 1e-4): SURVEY F9 -- the reference's own
+    # argmax is not stable there across thread counts, so parity tests report them separately
+    out_npz[tag + "/near_tie_idx"] = np.nonzero(npy(margin).reshape(-1) < 1e-4)[0].astype(np.int32)
+    if store_full:
+        out_npz[tag + "/x"] = npy(x)
+        out_npz[tag + "/t"] = npy(t).astype(np.int64)
+        out_npz[tag + "/logits"] = npy(pred)
+        out_npz[tag + "/eval_logits"] = npy(pred_eval)
+        for k, p in model.named_parameters():
+            if p.numel() <= 4096:
+                out_npz["%s/grad/%s" % (tag, k)] = npy(p.grad)
+            else:
+                out_npz["%s/grad_head/%s" % (tag, k)] = npy(p.grad.reshape(-1)[:64])
+        for k, v in sd1.items():
+            if "running" in k:
+                out_npz["%s/after/%s" % (tag, k)] = npy(v)
+    print(tag, "ce=%.8f reg=%.10f gnorm=%.8f hist=%s correct=%d hash=%s" %
+          (m["ce"], m["reg"], gnorm, m["argmax_hist"], m["correct"], m["sd_hash_init"]))
+
+
+def whole_net(ref, big=True):
+    out, meta = {}, {}
+    ROBO_S = dict(noScale=False, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128)
+    ROBO_L = dict(noScale=True, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128)
+    UNET_S = dict(noScale=False, planes=8, depth=4, levels=3, bellySize=0, bellyPlanes=128, pool=True)
+    UNET_L = dict(noScale=True, planes=8, depth=4, levels=3, bellySize=0, bellyPlanes=128, pool=True)
+    run_step(ref, ROBO_S, 2, 48, 64, True, "robo_s_2x48x64", out, meta)
+    run_step(ref, ROBO_L, 1, 48, 64, True, "robo_l_1x48x64", out, meta)
+    run_step(ref, UNET_S, 2, 48, 64, True, "unet_s_2x48x64", out, meta)
+    run_step(ref, UNET_L, 1, 32, 48, True, "unet_l_1x32x48", out, meta)
+    if big:
+        run_step(ref, ROBO_S, 4, 120, 160, False, "robo_s_4x120x160", out, meta)
+        run_step(ref, ROBO_L, 2, 480, 640, False, "robo_l_2x480x640", out, meta)
+        run_step(ref, UNET_L, 2, 480, 640, False, "unet_l_2x480x640", out, meta)
+    np.savez_compressed(os.path.join(HERE, "whole_net.npz"), **out)
+    with open(os.path.join(HERE, "whole_net.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def labelprop(ref):
+    """LabelProp (config 5).  The class cannot be constructed at HEAD (8 args passed to a
+    7-arg ConvPoolSimple.__init__), so the generator wraps the constructor to drop the extra
+    (dropout) argument; the arithmetic is untouched.  Weights: seeded random (the shipped .pth does
+    not travel); stored because the constructor's RNG order is part of the reference."""
+    orig = ref.ConvPoolSimple.__init__
+    def patched(self, inplanes, planes, size, stride, padding, dilation, bias, *_ignored):
+        orig(self, inplanes, planes, size, stride, padding, dilation, bias)
+    ref.ConvPoolSimple.__init__ = patched
+    try:
+        torch.manual_seed(12345678)
+        net = ref.LabelProp(5, 32, 0.0)
+    finally:
+        ref.ConvPoolSimple.__init__ = orig
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():     # make BN running stats / affine non-trivial, as a trained net has
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    net.eval()
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle.cpu_reference import labelprop_inputs
+    y_t = torch.randn(120, 160, generator=g)
+    y_n = y_t + 0.1 * torch.randn(120, 160, generator=g)
+    lab_t = torch.randint(0, 5, (120, 160), generator=g)
+    lab_n = torch.randint(0, 5, (120, 160), generator=g)
+    x = labelprop_inputs(y_t, y_n, lab_t, lab_n)
+    with torch.no_grad():
+        y = net(x.clone())
+    out = {"x": npy(x), "logits": npy(y), "argmax": npy(torch.max(y, 1)[1]).astype(np.uint8)}
+    for k, v in net.state_dict().items():
+        out["p/" + k] = npy(v)
+    np.savez_compressed(os.path.join(HERE, "labelprop.npz"), **out)
+    print("labelprop logits sum %.6f" % float(y.double().sum()))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(THREADS)
+    sys.path.insert(0, REF)
+    import model as ref          # the reference, imported (never copied)
+    which = sys.argv[1:] or ["layers", "net", "lp"]
+    if "layers" in which:
+        layer_kats(ref)
+    if "net" in which:
+        whole_net(ref)
+    if "lp" in which:
+        labelprop(ref)

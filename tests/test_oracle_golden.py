@@ -1,0 +1,119 @@
+"""CPU: the oracle (oracle/cpu_reference.py) against golden vectors produced by the imported reference
+(tests/golden/make_golden.py).  Bit-for-bit at 8 threads, the thread count the goldens were made at
+(the reference's own CPU output moves by ~1e-6 across thread counts)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sd_hash
+from oracle import cpu_reference as O
+import robocupvision_amd.model as M
+
+
+@pytest.fixture(autouse=True)
+def _threads():
+    old = torch.get_num_threads()
+    torch.set_num_threads(8)
+    yield
+    torch.set_num_threads(old)
+
+
+def _t(a):
+    a = np.asarray(a)
+    return torch.from_numpy(np.ascontiguousarray(a)).reshape(a.shape)
+
+
+def _block_sd(kats, name):
+    pre = name + "/p/"
+    return {k[len(pre):]: _t(kats[k]).clone() for k in kats.files if k.startswith(pre)}
+
+
+CONV_CASES = [("conv_3_8_s1", 1), ("conv_8_16_s2", 2), ("conv_16_16_s1", 1), ("conv_32_64_s2", 2), ("conv_64_64_s1", 1),
+              ("conv_128_128_s1", 1), ("conv_8_8_s1_odd", 1)]
+
+
+@pytest.mark.parametrize("name,stride", CONV_CASES)
+def test_conv_block(layer_kats, name, stride):
+    sd = _block_sd(layer_kats, name)
+    names = [k for k in sd if "running" not in k and "num_batches" not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    x = _t(layer_kats[name + "/x"]).requires_grad_(True)
+    y = O.conv_block(x, {("b." + k): v for k, v in sd.items()}, "b", stride, True)
+    assert torch.equal(y.detach(), _t(layer_kats[name + "/y_train"]))
+    y.backward(_t(layer_kats[name + "/gy"]))
+    assert torch.equal(x.grad, _t(layer_kats[name + "/gx"]))
+    for k in names:
+        assert torch.equal(sd[k].grad, _t(layer_kats["%s/g/%s" % (name, k)])), k
+    assert torch.equal(sd["bn.running_var"], _t(layer_kats[name + "/after/bn.running_var"]))
+    with torch.no_grad():
+        ye = O.conv_block(x, {("b." + k): v for k, v in sd.items()}, "b", stride, False)
+    assert torch.equal(ye, _t(layer_kats[name + "/y_eval"]))
+
+
+@pytest.mark.parametrize("name", ["up_16_8", "up_64_32", "up_128_64"])
+def test_up_block(layer_kats, name):
+    sd = _block_sd(layer_kats, name)
+    names = [k for k in sd if "running" not in k and "num_batches" not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    x = _t(layer_kats[name + "/x"]).requires_grad_(True)
+    y = O.up_block(x, {("b." + k): v for k, v in sd.items()}, "b", True)
+    assert torch.equal(y.detach(), _t(layer_kats[name + "/y_train"]))
+    y.backward(_t(layer_kats[name + "/gy"]))
+    assert torch.equal(x.grad, _t(layer_kats[name + "/gx"]))
+    for k in names:
+        assert torch.equal(sd[k].grad, _t(layer_kats["%s/g/%s" % (name, k)])), k
+
+
+def test_ce_and_argmax(layer_kats):
+    for name in ("ce_w", "ce_now"):
+        lg = _t(layer_kats[name + "/logits"]).requires_grad_(True)
+        t = _t(layer_kats[name + "/t"])
+        w = _t(layer_kats[name + "/w"]) if (name + "/w") in layer_kats.files else None
+        loss = O.cross_entropy_2d(lg, t, w)
+        assert torch.equal(loss.detach(), _t(layer_kats[name + "/loss"]))
+        loss.backward()
+        assert torch.equal(lg.grad, _t(layer_kats[name + "/glogits"]))
+        assert torch.equal(torch.max(lg, 1)[1], _t(layer_kats[name + "/argmax"]))
+    assert int(layer_kats["tie/argmax"].reshape(-1)[0]) == 1      # first maximum wins
+
+
+def _cfg(ctor):
+    return O.NetConfig(**{k: v for k, v in ctor.items()})
+
+
+SMALL = ["robo_s_2x48x64", "robo_l_1x48x64", "unet_s_2x48x64", "unet_l_1x32x48"]
+
+
+@pytest.mark.parametrize("tag", SMALL + ["robo_s_4x120x160"])
+def test_whole_net_step(net_kats, net_meta, tag):
+    m = net_meta[tag]
+    torch.manual_seed(12345678)
+    model = M.ROBO_UNet(**m["ctor"])
+    sd = model.state_dict()
+    assert sd_hash(sd) == m["sd_hash_init"]          # same construction order => same init as the reference
+    st = O.TrainState(sd, _cfg(m["ctor"]))
+    x, t = O.synthetic_batch(m["B"], m["H"], m["W"])
+    if (tag + "/x") in net_kats.files:
+        assert torch.equal(x, _t(net_kats[tag + "/x"])) and torch.equal(t, _t(net_kats[tag + "/t"]))
+    res = O.train_step(st, x, t)
+    assert res["ce"] == m["ce"] and res["reg"] == m["reg"]
+    assert res["correct"] == m["correct"]
+    assert np.array_equal(res["pred_class"].numpy().astype(np.uint8), net_kats[tag + "/argmax"])
+    if (tag + "/logits") in net_kats.files:
+        assert torch.equal(res["pred"], _t(net_kats[tag + "/logits"]))
+    # optimizer step + BN running stats: state dict after the step hashes like the reference's
+    sd_after = {k: v.detach() for k, v in st.sd.items()}
+    assert sd_hash(sd_after) == m["sd_hash_after_step"]
+    with torch.no_grad():
+        pe = O.robo_unet_forward(sd_after, x, st.cfg, training=False)
+    assert abs(float(pe.double().sum()) - m["eval_logits_sum"]) < 1e-9 * max(1.0, abs(m["eval_logits_sum"]))
+    assert np.array_equal(torch.max(pe, 1)[1].numpy().astype(np.uint8), net_kats[tag + "/eval_argmax"])
+
+
+def test_conv_macs_match_survey():
+    # forward GFLOP per image = 2*MAC
+    s = O.conv_macs(O.NetConfig(), 120, 160)[0]
+    l = O.conv_macs(O.NetConfig(noScale=True), 480, 640)[0]
+    assert abs(2 * s / 1e9 - 0.4964) < 5e-4 and abs(2 * l / 1e9 - 4.7579) < 5e-4
