@@ -159,6 +159,15 @@ int rcv_op_workspace(const rcv_handle* h, rcv_op* op, size_t* part_bytes);
 /* Enqueue ops[0..n) in order on `stream`. */
 int rcv_run(rcv_handle* h, const rcv_op* ops, int n, void* stream);
 
+/* Profiling aid (not for the training path: it creates HIP events and synchronises the stream):
+ * runs ops[0..n) like rcv_run with a hipEvent pair around every op and writes the elapsed
+ * milliseconds of op k to ms[k] (host memory). */
+int rcv_run_timed(rcv_handle* h, const rcv_op* ops, int n, void* stream, float* ms);
+
+/* Label of the kernel (template instantiation / tiling) the library launches for `op`, e.g.
+ * "conv_mfma<2,5,4,1,8>" -- written NUL-terminated into buf[0..size). */
+int rcv_op_kernel_label(const rcv_handle* h, const rcv_op* op, char* buf, int size);
+
 /* One row of the RCV_OP_PACK job table (device memory, p[RCV_P_IN] -> rcv_pack_job[count]). */
 typedef struct rcv_pack_job {
   const float* src;   /* parameter tensor [D0][D1][3][3]                                          */

@@ -37,6 +37,7 @@ class RcvPackJob(C.Structure):
 
 EXPORTS = [
     "rcv_create", "rcv_destroy", "rcv_last_error", "rcv_version", "rcv_num_cus", "rcv_op_workspace", "rcv_run",
+    "rcv_run_timed", "rcv_op_kernel_label",
     "rcv_conv3x3", "rcv_convT3x3s2", "rcv_wgrad3x3", "rcv_bn_finalize", "rcv_bn_backward", "rcv_maxpool2x2_fwd",
     "rcv_softmax_ce_argmax_fwd", "rcv_softmax_ce_bwd", "rcv_adam_l1_step",
 ]
@@ -69,6 +70,8 @@ def load():
         lib.rcv_num_cus.argtypes = [C.c_void_p]
         lib.rcv_op_workspace.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.POINTER(C.c_size_t)]
         lib.rcv_run.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_int, C.c_void_p]
+        lib.rcv_run_timed.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+        lib.rcv_op_kernel_label.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_char_p, C.c_int]
         for name in ("rcv_conv3x3", "rcv_convT3x3s2", "rcv_wgrad3x3"):
             getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_void_p]
         _lib = lib
@@ -125,3 +128,18 @@ class OpList:
     def run(self, h, stream_ptr: int):
         if self.n:
             check(load().rcv_run(h, self.arr, self.n, C.c_void_p(stream_ptr)), "rcv_run")
+
+    def run_timed(self, h, stream_ptr: int):
+        """Profiling aid: per-op milliseconds (HIP events around every op; synchronises)."""
+        ms = (C.c_float * max(self.n, 1))()
+        if self.n:
+            check(load().rcv_run_timed(h, self.arr, self.n, C.c_void_p(stream_ptr), ms), "rcv_run_timed")
+        return [float(ms[k]) for k in range(self.n)]
+
+    def labels(self, h):
+        out = []
+        buf = C.create_string_buffer(64)
+        for k in range(self.n):
+            check(load().rcv_op_kernel_label(h, C.byref(self.arr[k]), buf, 64), "rcv_op_kernel_label")
+            out.append(buf.value.decode())
+        return out

@@ -59,7 +59,8 @@ static int dispatch(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
 
 int rcv_op_workspace(const rcv_handle* h, rcv_op* op, size_t* part_bytes) {
   RCV_CHECK_ARG(h && op && part_bytes, "rcv_op_workspace: NULL argument");
-  OpQuery q = {0, 0, 0};
+  OpQuery q;
+  memset(&q, 0, sizeof(q));
   const int rc = dispatch(h, op, nullptr, &q);
   if (rc) return rc;
   op->i[RCV_I_NPART] = q.n_part;
@@ -82,6 +83,38 @@ int rcv_run(rcv_handle* h, const rcv_op* ops, int n, void* stream) {
     }
   }
   return RCV_OK;
+}
+
+int rcv_op_kernel_label(const rcv_handle* h, const rcv_op* op, char* buf, int size) {
+  RCV_CHECK_ARG(h && op && buf && size > 0, "rcv_op_kernel_label: bad arguments");
+  OpQuery q;
+  memset(&q, 0, sizeof(q));
+  const int rc = dispatch(h, op, nullptr, &q);
+  if (rc) return rc;
+  strncpy(buf, q.label, size - 1);
+  buf[size - 1] = 0;
+  return RCV_OK;
+}
+
+int rcv_run_timed(rcv_handle* h, const rcv_op* ops, int n, void* stream, float* ms) {
+  RCV_CHECK_ARG(h && ops && n > 0 && ms, "rcv_run_timed: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t* ev = new hipEvent_t[n + 1];
+  for (int k = 0; k <= n; ++k) {
+    if (hipEventCreate(&ev[k]) != hipSuccess) { rcv_set_error("rcv_run_timed: hipEventCreate failed"); delete[] ev; return RCV_E_HIP; }
+  }
+  int rc = RCV_OK;
+  hipEventRecord(ev[0], s);
+  for (int k = 0; k < n && rc == RCV_OK; ++k) {
+    rc = dispatch(h, &ops[k], s, nullptr);
+    hipEventRecord(ev[k + 1], s);
+  }
+  if (hipStreamSynchronize(s) != hipSuccess && rc == RCV_OK) { rcv_set_error("rcv_run_timed: stream sync failed"); rc = RCV_E_HIP; }
+  if (rc == RCV_OK)
+    for (int k = 0; k < n; ++k) hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]);
+  for (int k = 0; k <= n; ++k) hipEventDestroy(ev[k]);
+  delete[] ev;
+  return rc;
 }
 
 // ------------------------------ named entry points ------------------------------

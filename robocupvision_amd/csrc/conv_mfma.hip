@@ -458,6 +458,9 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   const int Cout = op->i[RCV_I_COUT];
   const int n_part = pl.grid.x * pl.grid.z;
   if (query) {
+    const TileCfg& tc = kTiles[pl.tile];
+    snprintf(query->label, sizeof(query->label), "%s_mfma<%d,%d,%d,%d,%d>", transposed ? "tconv" : "conv", tc.WM, tc.WN, tc.WAVES_M,
+             tc.WAVES_N, pl.CK);
     query->n_part = op->i[RCV_I_STATS] != RCV_STATS_NONE ? n_part : 0;
     query->n_split = 0;
     query->part_bytes = (size_t)query->n_part * 2 * Cout * sizeof(float);

@@ -55,6 +55,7 @@ struct OpQuery {
   int n_part;
   int n_split;
   size_t part_bytes;
+  char label[64];
 };
 int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query);
 int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query);

@@ -564,7 +564,13 @@ static inline int reduce_grid(const rcv_handle* h, size_t work_items, int block)
 int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query) {
   const int N = op->i[RCV_I_N], H = op->i[RCV_I_H], W = op->i[RCV_I_W];
   const int Cin = op->i[RCV_I_CIN], Cout = op->i[RCV_I_COUT];
-  if (query) { query->n_part = 0; query->n_split = 0; query->part_bytes = 0; }
+  if (query) {
+    static const char* names[] = {"?", "conv", "tconv", "wgrad", "wgrad_reduce", "pack", "bn_finalize", "bn_eval", "bn_bwd", "combine",
+                                  "cls_fwd", "cls_bwd", "ce_fwd", "ce_bwd", "pool_fwd", "pool_bwd", "adam_l1", "memset", "conv1x1",
+                                  "add_slice", "materialize", "bwd_stats"};
+    query->n_part = 0; query->n_split = 0; query->part_bytes = 0;
+    snprintf(query->label, sizeof(query->label), "%s", (op->kind > 0 && op->kind <= 21) ? names[op->kind] : "?");
+  }
   switch (op->kind) {
     case RCV_OP_PACK: {
       if (query) return RCV_OK;

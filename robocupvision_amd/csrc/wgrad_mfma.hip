@@ -371,7 +371,7 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
 
 int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query) {
   if (op->kind == RCV_OP_WGRAD_REDUCE) {
-    if (query) { query->n_part = 0; query->n_split = 0; query->part_bytes = 0; return RCV_OK; }
+    if (query) { snprintf(query->label, sizeof(query->label), "wgrad_reduce"); query->n_part = 0; query->n_split = 0; query->part_bytes = 0; return RCV_OK; }
     const int CA = op->i[RCV_I_CIN], CB = op->i[RCV_I_COUT], nsplit = op->i[RCV_I_NSPLIT];
     const int CAP = round_up(CA, 16), CBP = round_up(CB, 16);
     const float* part = (const float*)op->p[RCV_P_PART];
@@ -388,6 +388,8 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   int rc = wmake_plan(h, op, &pl);
   if (rc) return rc;
   if (query) {
+    const WTile& wt = kWT[pl.tile];
+    snprintf(query->label, sizeof(query->label), "wgrad_mfma<%d,%d,%d,%d,%d>", wt.WM, wt.WN, wt.WAVES_M, wt.WAVES_N, wt.WAVES_K);
     query->n_part = 0;
     query->n_split = pl.nsplit;
     query->part_bytes = (size_t)pl.nsplit * (9 * (size_t)pl.CBP * pl.CAP + pl.CBP) * sizeof(float);

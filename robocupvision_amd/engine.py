@@ -514,6 +514,45 @@ class Engine:
         self._last = (plan, [t for t in inputs])
         return plan.logits
 
+    def profile_last(self, reps: int = 3):
+        """Profiling aid for bench.py: re-runs the last forward (+ backward) plan with a HIP event pair around
+        every op (rcv_run_timed) and returns rows of (label, kind, avg ms, algorithmic FLOPs, algorithmic bytes)."""
+        plan, _inputs = self._last
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        lists = [plan.fwd]
+        if plan.bwd is not None and plan.bwd.n:
+            dl = torch.full_like(plan.logits, 1e-4)
+            for (idx, slot) in plan.dlogits_slots:
+                plan.bwd.arr[idx].p[slot] = dl.data_ptr()
+            lists.append(plan.bwd)
+        rows = []
+        for lst in lists:
+            labels = lst.labels(self.handle)
+            acc = [0.0] * lst.n
+            for _ in range(reps):
+                for k, v in enumerate(lst.run_timed(self.handle, stream)):
+                    acc[k] += v
+            for k in range(lst.n):
+                op = lst.arr[k]
+                i = op.i
+                n, h, w, cin, cout, ho, wo = (i[L.RCV_I_N], i[L.RCV_I_H], i[L.RCV_I_W], i[L.RCV_I_CIN], i[L.RCV_I_COUT],
+                                              i[L.RCV_I_HO], i[L.RCV_I_WO])
+                flops, nbytes = 0.0, 0.0
+                two = lambda mode: 2 if mode in (L.LOAD_GRAD_ENC, L.LOAD_GRAD_DEC) else 1
+                if op.kind == L.OP_CONV:
+                    flops = 2.0 * 9 * cin * cout * n * ho * wo
+                    extra = (1 if op.flags & L.F_RESID else 0) + (1 if i[L.RCV_I_STATS] in (L.STATS_BWD_ENC, L.STATS_BWD_DEC) else 0)
+                    nbytes = 4.0 * (n * h * w * cin * two(i[L.RCV_I_INMODE]) + n * ho * wo * cout * (1 + extra))
+                elif op.kind == L.OP_TCONV:
+                    flops = 2.0 * 9 * cin * cout * n * h * w
+                    extra = (1 if op.flags & L.F_RESID else 0) + (1 if i[L.RCV_I_STATS] in (L.STATS_BWD_ENC, L.STATS_BWD_DEC) else 0)
+                    nbytes = 4.0 * (n * h * w * cin * two(i[L.RCV_I_INMODE]) + n * ho * wo * cout * (1 + extra))
+                elif op.kind == L.OP_WGRAD:
+                    flops = 2.0 * 9 * cin * cout * n * ho * wo
+                    nbytes = 4.0 * (n * h * w * cin * two(i[L.RCV_I_INMODE]) + n * ho * wo * cout * two(i[L.RCV_I_INMODE2]))
+                rows.append({"label": labels[k], "kind": int(op.kind), "ms": acc[k] / reps, "flops": flops, "bytes": nbytes})
+        return rows
+
     def backward(self, dlogits: torch.Tensor):
         plan, _inputs = self._last
         if plan.bwd is None or plan.bwd.n == 0:

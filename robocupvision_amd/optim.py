@@ -1,0 +1,85 @@
+"""Fused caller-side step pieces: Adam + the L1 term's gradient in one launch.
+
+The reference adds ``decay * sum|p|`` to the loss (train.py:23-27,52-55) and lets autograd produce
+``decay*sign(p)`` for every one of its 62-74 parameter tensors, then steps ``torch.optim.Adam`` over 5
+parameter groups (train.py:357-363).  Here the parameters and their gradients already live in two flat
+HBM buffers (engine.FlatParams), so the same update is ONE kernel (RCV_OP_ADAM_L1) over ~1.1 M floats.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def reference_param_groups(model, lr: float, transfer: int = 0):
+    """The five groups of train.py:357-363 (group 0 = downPart[0:transfer] at 10x lr)."""
+    return [{"params": list(model.downPart[0:transfer].parameters()), "lr": lr * 10},
+            {"params": list(model.downPart[transfer:].parameters())},
+            {"params": list(model.PB.parameters())},
+            {"params": list(model.upPart.parameters())},
+            {"params": list(model.segmenter.parameters())}]
+
+
+class AdamL1(torch.optim.Optimizer):
+    """torch.optim.Adam(betas=(.9,.999), eps=1e-8) + gradient of ``decay*sum|p|``, fused.
+
+    It is a ``torch.optim.Optimizer`` (param_groups with per-group ``lr``), so the stock schedulers the
+    reference uses (CosineAnnealingLR, train.py:366) drive it unchanged.  ``grad_scale`` multiplies the
+    stored gradient first (1/world_size after a summing all-reduce)."""
+
+    def __init__(self, model, lr: float = 1e-3, decay: float = 0.0, transfer: int = 0, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.model = model
+        self.decay = float(decay)
+        self.grad_scale = 1.0
+        self._m: Optional[torch.Tensor] = None
+        self._v: Optional[torch.Tensor] = None
+        self._t = 0
+        self._lr_elem = None
+        self._lr_key = None
+        super().__init__(reference_param_groups(model, lr, transfer), dict(lr=lr, betas=betas, eps=eps))
+
+    def _flat(self):
+        eng = self.model._get_engine()
+        if eng.flat is None:
+            raise L.RcvError("AdamL1.step() before the first forward: the engine has not laid out the parameters yet")
+        return eng, eng.flat
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        eng, fl = self._flat()
+        if self._m is None or self._m.numel() != fl.numel or self._m.device != fl.data.device:
+            self._m = torch.zeros_like(fl.data)
+            self._v = torch.zeros_like(fl.data)
+        # gradients normally ARE views of fl.grad; copy in the ones autograd had to clone (accumulation)
+        for k, p in enumerate(fl.params):
+            if p.grad is not None:
+                view = fl.grad_view(k)
+                if p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+        lrs = [(g["lr"], g["params"]) for g in self.param_groups if len(g["params"])]
+        uniform = all(abs(lr - lrs[0][0]) == 0.0 for lr, _ in lrs)
+        lr_elem_ptr = 0
+        if not uniform:
+            key = tuple(lr for lr, _ in lrs)
+            if key != self._lr_key:
+                t = torch.zeros_like(fl.data)
+                for lr, params in lrs:
+                    for p in params:
+                        k = fl.index(p)
+                        t[fl.offsets[k]:fl.offsets[k] + p.numel()] = lr
+                self._lr_elem, self._lr_key = t, key
+            lr_elem_ptr = self._lr_elem.data_ptr()
+        self._t += 1
+        b1, b2 = self.defaults["betas"]
+        op = L.make_op(L.OP_ADAM_L1, 0, count=fl.numel, aux0=self._t, f0=lrs[0][0], f1=b1, f2=b2, f3=self.defaults["eps"],
+                       f4=self.decay, f5=self.grad_scale, p_in=fl.data.data_ptr(), p_in2=fl.grad.data_ptr(),
+                       p_x0=self._m.data_ptr(), p_x1=self._v.data_ptr(), p_x2=lr_elem_ptr)
+        L.OpList([op]).run(eng.handle, torch.cuda.current_stream(fl.data.device).cuda_stream)
+
+    def l1_term(self) -> torch.Tensor:
+        """decay * sum|p| (what train.py:53 logs as `reg`), one reduction over the flat buffer."""
+        _, fl = self._flat()
+        return self.decay * fl.data.abs().sum()

@@ -1,0 +1,99 @@
+"""Counterpart of the reference's training-step body (train.py:43-74) for the HIP path, single GPU
+or data parallel (one process per GPU, RCCL all-reduce of the flat gradient buffer over xGMI).
+
+    trainer = Trainer(model.cuda(), class_weights=[1,10,30,10,2], lr=1e-3, decay=1e-6)
+    for imgs, targets in loader:
+        trainer.step(imgs.cuda(), targets.cuda())
+    print(trainer.pop_metrics())
+
+The reference's three per-step ``.item()`` host syncs (train.py:70-73) are replaced by on-device
+accumulation of (loss, reg, #correct pixels); ``pop_metrics()`` reads them once per epoch.
+
+Data-parallel semantics (the reference is single device): BatchNorm statistics are per
+rank, the weighted-CE normaliser is per rank, gradients are averaged over ranks, every rank applies the
+identical optimizer step, running BN buffers stay per rank (rank 0 is authoritative for checkpoints).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from .model import CrossEntropyLoss2d
+from .optim import AdamL1
+
+
+class Trainer:
+    def __init__(self, model, class_weights: Optional[Sequence[float]] = (1, 10, 30, 10, 2), lr: float = 1e-3,
+                 decay: float = 1e-6, transfer: int = 0, distributed: bool = False, overlap: bool = True):
+        self.model = model
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise L.RcvError("Trainer needs the model on the HIP device (model.cuda())")
+        self.device = dev
+        w = None if class_weights is None else torch.tensor(list(class_weights), dtype=torch.float32, device=dev)
+        self.criterion = CrossEntropyLoss2d(w).to(dev)
+        self.optimizer = AdamL1(model, lr=lr, decay=decay, transfer=transfer)
+        self.metrics = torch.zeros(4, dtype=torch.float64, device=dev)     # loss, reg, correct, steps
+        self.distributed = distributed
+        self.world = 1
+        self.comm_stream = None
+        if distributed:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise L.RcvError("distributed=True needs torch.distributed.init_process_group('nccl') first")
+            self.world = dist.get_world_size()
+            self.optimizer.grad_scale = 1.0 / self.world
+            self.comm_stream = torch.cuda.Stream(device=dev) if overlap else None
+            # identical parameters on every rank before the first step
+            for p in model.parameters():
+                dist.broadcast(p.data, 0)
+
+    def _allreduce_grads(self):
+        import torch.distributed as dist
+        fl = self.model._get_engine().flat
+        if self.comm_stream is None:
+            dist.all_reduce(fl.grad)
+            return
+        # exchange on a side stream so the L1 reduction / metric bookkeeping of this step (and, in the
+        # bucketed variant, the rest of backward) runs beside it; the optimizer waits on the event
+        cur = torch.cuda.current_stream(self.device)
+        self.comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self.comm_stream):
+            dist.all_reduce(fl.grad)
+        self._pending = self.comm_stream
+
+    def step(self, imgs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
+        """One train.py:43-74 iteration; returns the logits tensor (engine-owned, valid until the next forward)."""
+        model, opt, crit = self.model, self.optimizer, self.criterion
+        model.train()
+        opt.zero_grad(set_to_none=True)
+        pred = model(imgs)
+        ce = crit(pred, targets)
+        ce.backward()
+        self._pending = None
+        if self.distributed and self.world > 1:
+            self._allreduce_grads()
+        with torch.no_grad():
+            reg = opt.l1_term()
+            self.metrics += torch.stack([ce.detach().double() + reg.double(), reg.double(),
+                                         crit.last_stats[2].double(), torch.ones((), dtype=torch.float64, device=self.device)])
+        if self._pending is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._pending)
+        opt.step()
+        return pred
+
+    @torch.no_grad()
+    def evaluate(self, imgs: torch.Tensor, targets: torch.Tensor):
+        """valid() forward (train.py:102-131): eval-mode BN, CE, arg-max mask."""
+        self.model.eval()
+        pred = self.model(imgs)
+        loss = self.criterion(pred, targets)
+        return pred, loss, self.criterion.last_argmax
+
+    def pop_metrics(self) -> dict:
+        m = self.metrics.cpu().tolist()
+        self.metrics.zero_()
+        n = max(m[3], 1.0)
+        return {"loss": m[0] / n, "reg": m[1] / n, "correct_pixels": m[2], "steps": int(m[3])}

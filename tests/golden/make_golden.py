@@ -179,6 +179,23 @@ def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta):
         "grad_summary": gsum,
         "param_after_step_sum": {k: float(v.double().sum()) for k, v in sd1.items() if v.dtype.is_floating_point},
     }
+    # the same step evaluated by the reference in float64: the exact value the fp32 paths approximate.
+    # Several gradients are sums with heavy cancellation (biases ahead of BN, BN affine of wide layers):
+    # the fp32 reference itself is off by up to ~2e-3 relative there, so parity tests judge against these.
+    torch.manual_seed(12345678)
+    model64 = ref.ROBO_UNet(**ctor_kwargs).double()
+    crit64 = ref.CrossEntropyLoss2d(torch.tensor([1, 10, 30, 10, 2], dtype=torch.float64))
+    model64.train()
+    pred64 = model64(x.double())
+    ce64 = crit64(pred64, t)
+    reg64 = 0
+    for p in model64.parameters():
+        reg64 = reg64 + torch.sum(torch.abs(p))
+    (ce64 + decay * reg64).backward()
+    m["fp64"] = {"ce": float(ce64), "logits_sum": float(pred64.sum()), "logits_abs_sum": float(pred64.abs().sum()),
+                 "grad_norm": float(torch.sqrt(sum((p.grad ** 2).sum() for p in model64.parameters()))),
+                 "grad_summary": grad_summary(model64),
+                 "max_logit_err_fp32_ref": float((pred64 - pred.double()).abs().max())}
     meta[tag] = m
     out_npz[tag + "/argmax"] = npy(pc).astype(np.uint8)
     out_npz[tag + "/eval_argmax"] = npy(torch.max(pred_eval, 1)[1]).astype(np.uint8)

@@ -1,0 +1,124 @@
+"""GPU: every block of the hot path through the C ABI against golden vectors of the imported reference
+(layer KATs, tests/golden/layer_kats.npz) -- forward (train + eval), data / filter / bias / BatchNorm
+gradients, running statistics.  Tolerance: 1e-3 relative (BASELINE.json north_star), checked as
+|a-b| <= 1e-3*|b| + 1e-3*max|b|*1e-2 so that values near zero are judged against the tensor scale."""
+import numpy as np
+import pytest
+import torch
+
+import robocupvision_amd.model as M
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    a = np.asarray(a)
+    return torch.from_numpy(np.ascontiguousarray(a)).reshape(a.shape)
+
+
+def close(a, b, what, rtol=1e-3, floor=1e-2):
+    """|a-b| <= rtol*|b| + rtol*floor*max|b|.  floor=1e-2 for activations; gradients (sums with heavy
+    cancellation, where fp32 summation order alone moves small entries) use floor=1: 1e-3 of the tensor scale."""
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+    scale = float(b.abs().max()) + 1e-30
+    err = (a - b).abs()
+    bound = rtol * b.abs() + rtol * floor * scale
+    bad = err > bound
+    assert not bool(bad.any()), "%s: %d/%d elements off, max err %.3e (scale %.3e), worst rel-to-scale %.3e" % (
+        what, int(bad.sum()), bad.numel(), float(err.max()), scale, float(err.max()) / scale)
+
+
+def _load_block(kats, name, mod):
+    pre = name + "/p/"
+    sd = {k[len(pre):]: _t(kats[k]) for k in kats.files if k.startswith(pre)}
+    mod.load_state_dict(sd)
+    return mod.to(DEV)
+
+
+CONV_CASES = [("conv_3_8_s1", 3, 8, 1), ("conv_8_16_s2", 8, 16, 2), ("conv_16_16_s1", 16, 16, 1), ("conv_32_64_s2", 32, 64, 2),
+              ("conv_64_64_s1", 64, 64, 1), ("conv_128_128_s1", 128, 128, 1), ("conv_8_8_s1_odd", 8, 8, 1)]
+
+
+def _run_block(layer_kats, name, mod, check_gx=True):
+    x = _t(layer_kats[name + "/x"]).to(DEV).requires_grad_(True)
+    mod.train()
+    y = mod(x)
+    close(y, _t(layer_kats[name + "/y_train"]), name + " y_train")
+    y.backward(_t(layer_kats[name + "/gy"]).to(DEV))
+    torch.cuda.synchronize()
+    for k, p in mod.named_parameters():
+        ref = _t(layer_kats["%s/g/%s" % (name, k)])
+        if k == "conv.bias" and isinstance(mod, M.upSampleTransposeConv):
+            # bias ahead of BatchNorm: exact gradient is 0; the reference returns rounding noise
+            assert float(p.grad.abs().max()) == 0.0 and float(ref.abs().max()) < 1e-4
+            continue
+        close(p.grad, ref, "%s grad %s" % (name, k), floor=1.0)
+    if check_gx:
+        close(x.grad, _t(layer_kats[name + "/gx"]), name + " gx", floor=1.0)
+    close(mod.bn.running_mean, _t(layer_kats[name + "/after/bn.running_mean"]), name + " running_mean")
+    close(mod.bn.running_var, _t(layer_kats[name + "/after/bn.running_var"]), name + " running_var")
+    assert int(mod.bn.num_batches_tracked) == 1
+    mod.eval()
+    with torch.no_grad():
+        ye = mod(x.detach())
+    close(ye, _t(layer_kats[name + "/y_eval"]), name + " y_eval")
+
+
+@pytest.mark.parametrize("name,cin,cout,stride", CONV_CASES)
+def test_conv_block(layer_kats, name, cin, cout, stride):
+    if cin % 4:
+        pytest.skip("3-channel input is the NCHW image path, covered by the whole-net tests")
+    mod = _load_block(layer_kats, name, M.Conv(cin, cout, 3, stride))
+    _run_block(layer_kats, name, mod)
+
+
+@pytest.mark.parametrize("name,cin,cout", [("up_16_8", 16, 8), ("up_64_32", 64, 32), ("up_128_64", 128, 64)])
+def test_up_block(layer_kats, name, cin, cout):
+    mod = _load_block(layer_kats, name, M.upSampleTransposeConv(cin, cout))
+    _run_block(layer_kats, name, mod)
+
+
+@pytest.mark.parametrize("name,cin,cout,s,d", [("cps_32_64_d2", 32, 64, 1, 2), ("cps_8_16_s2", 8, 16, 2, 1)])
+def test_dilated_block_eval(layer_kats, name, cin, cout, s, d):
+    mod = _load_block(layer_kats, name, M.ConvPoolSimple(cin, cout, 3, s, d, d, False))
+    # the golden's eval output uses the running statistics AFTER its one training step
+    mod.bn.running_mean.copy_(_t(layer_kats[name + "/after/bn.running_mean"]))
+    mod.bn.running_var.copy_(_t(layer_kats[name + "/after/bn.running_var"]))
+    mod.eval()
+    with torch.no_grad():
+        y = mod(_t(layer_kats[name + "/x"]).to(DEV))
+    close(y, _t(layer_kats[name + "/y_eval"]), name + " y_eval")
+
+
+@pytest.mark.parametrize("name", ["ce_w", "ce_now"])
+def test_cross_entropy(layer_kats, name):
+    w = _t(layer_kats[name + "/w"]) if (name + "/w") in layer_kats.files else None
+    crit = M.CrossEntropyLoss2d(w).to(DEV)
+    lg = _t(layer_kats[name + "/logits"]).to(DEV).requires_grad_(True)
+    t = _t(layer_kats[name + "/t"]).to(DEV)
+    loss = crit(lg, t)
+    ref = float(layer_kats[name + "/loss"])
+    assert abs(float(loss) - ref) <= 1e-5 * abs(ref)
+    loss.backward()
+    close(lg.grad, _t(layer_kats[name + "/glogits"]), name + " dlogits", rtol=1e-4)
+    # mask: bit exact (integer work)
+    assert np.array_equal(crit.last_argmax.cpu().numpy(), layer_kats[name + "/argmax"].astype(np.uint8))
+    assert int(crit.last_stats[2]) == int((layer_kats[name + "/argmax"] == layer_kats[name + "/t"]).sum())
+
+
+def test_argmax_tie_rule():
+    lg = torch.tensor([1.0, 3.0, 3.0, 2.0], device=DEV).view(1, 4, 1, 1)
+    crit = M.CrossEntropyLoss2d().to(DEV)
+    crit(lg, torch.zeros(1, 1, 1, dtype=torch.long, device=DEV))
+    assert int(crit.last_argmax.view(-1)[0]) == 1     # first maximum wins (train.py:70 torch.max)
+
+
+def test_empty_and_bad_shapes_raise():
+    m = M.ROBO_UNet().to(DEV)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 20, 24, device=DEV))       # not a multiple of 8
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 4, 16, 16, device=DEV))
