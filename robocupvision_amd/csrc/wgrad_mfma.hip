@@ -256,24 +256,42 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
 }
 
 // dW[cb][ca][tap] = sum_split part[split][tap][cb][ca];  db[cb] = sum_split part_bias[split][cb]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_bias, float* __restrict__ dw,
-                                    float* __restrict__ db, int nsplit, int CB, int CA, int CBP, int CAP) {
-  const int total = 9 * CB * CA;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < total) {
-    const int ca = e % CA;
-    const int cb = (e / CA) % CB;
-    const int t = e / (CA * CB);
-    float u = 0.f;
-    const size_t stride = (size_t)9 * CBP * CAP;
-    const float* src = part + ((size_t)t * CBP + cb) * CAP + ca;
-    for (int sidx = 0; sidx < nsplit; ++sidx) u += src[sidx * stride];
-    dw[((size_t)cb * CA + ca) * 9 + t] = u;
-  } else if (db && e < total + CB) {
-    const int cb = e - total;
-    float u = 0.f;
-    for (int sidx = 0; sidx < nsplit; ++sidx) u += part_bias[(size_t)sidx * CBP + cb];
-    db[cb] = u;
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_bias,
+                                                           float* __restrict__ dw, float* __restrict__ db, int nsplit, int CB, int CA,
+                                                           int CBP, int CAP) {
+  // 64 consecutive partial-layout elements x 4 split groups per workgroup; every thread keeps 4 loads in
+  // flight; the order of additions is a fixed function of (nsplit) => bitwise reproducible.
+  __shared__ float sh[4][64];
+  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int totalP = 9 * CBP * CAP;
+  const int e = blockIdx.x * 64 + el;
+  const size_t stride = (size_t)totalP;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const float* src = nullptr;
+  size_t st = 0;
+  if (e < totalP) { src = part + e; st = stride; }
+  else if (part_bias && e < totalP + CBP) { src = part_bias + (e - totalP); st = (size_t)CBP; }
+  if (src) {
+    int sidx = grp;
+    for (; sidx + 12 < nsplit; sidx += 16) {
+      a0 += src[(size_t)sidx * st]; a1 += src[(size_t)(sidx + 4) * st];
+      a2 += src[(size_t)(sidx + 8) * st]; a3 += src[(size_t)(sidx + 12) * st];
+    }
+    for (; sidx < nsplit; sidx += 4) a0 += src[(size_t)sidx * st];
+  }
+  sh[grp][el] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && src) {
+    const float u = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
+    if (e < totalP) {
+      const int ca = e % CAP;
+      const int cb = (e / CAP) % CBP;
+      const int t = e / (CAP * CBP);
+      if (ca < CA && cb < CB) dw[((size_t)cb * CA + ca) * 9 + t] = u;
+    } else {
+      const int cb = e - totalP;
+      if (db && cb < CB) db[cb] = u;
+    }
   }
 }
 
@@ -379,8 +397,8 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     float* db = (float*)op->p[RCV_P_BIAS];
     RCV_CHECK_ARG(part && dw && nsplit > 0, "wgrad_reduce: null operand");
     const float* pb = db ? part + (size_t)nsplit * 9 * CBP * CAP : nullptr;
-    const int total = 9 * CB * CA + (db ? CB : 0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, s, part, pb, dw, db, nsplit, CB, CA, CBP, CAP);
+    const int total = 9 * CBP * CAP + (db ? CBP : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ceil_div(total, 64)), dim3(256), 0, s, part, pb, dw, db, nsplit, CB, CA, CBP, CAP);
     RCV_HIP(hipGetLastError());
     return RCV_OK;
   }
