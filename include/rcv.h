@@ -108,6 +108,8 @@ enum {
 #define RCV_F_TRANSPOSED_SRC 32u /* PACK / WGRAD_REDUCE: parameter is [Cin][Cout][3][3] (convT)  */
 #define RCV_F_ARGMAX    64u   /* CE_FWD: also write argmax mask and count correct pixels          */
 #define RCV_F_TRAINING  128u  /* BN_FINALIZE: update running stats                                */
+#define RCV_F_DBG_NOSTAGE (1u << 20) /* profiling ablation: skip the global->LDS input staging (results are garbage) */
+#define RCV_F_DBG_NOMFMA  (1u << 21) /* profiling ablation: skip the MFMA contraction (results are garbage)          */
 
 /* integer slots */
 enum {
@@ -121,7 +123,7 @@ enum {
   RCV_I_NPART,                            /* rows of `part` (filled by rcv_op_workspace)          */
   RCV_I_NSPLIT,                           /* WGRAD: pixel splits (filled by rcv_op_workspace)     */
   RCV_I_COUNT,                            /* element / job count for table driven ops             */
-  RCV_I_AUX0, RCV_I_AUX1,
+  RCV_I_AUX0, RCV_I_AUX1,                 /* TCONV: AUX0 = 1 when the filter is packed in the merged-parity layout */
   RCV_I__N = 20
 };
 
@@ -176,6 +178,8 @@ typedef struct rcv_pack_job {
   int32_t rows_from_d1;   /* 1: rows (contraction channel) = d1, cols = d0; 0: rows = d0, cols=d1 */
   int32_t flip;           /* 1: tap t reads source tap 8-t                                        */
   int32_t rows_pad, cols_pad;
+  int32_t merged;         /* 1: transposed-conv "merged parity" layout [4 taps (dy,dx)][rows][4*cols] (see conv_mfma.hip) */
+  int32_t reserved;
 } rcv_pack_job;
 
 /* ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,385 @@
+// Narrow-layer 3x3 convolution (few channels, large planes): the HBM-bound end of the ROBO-UNet step.
+//
+// Same implicit GEMM and MFMA lane mapping as conv_mfma.hip (D[co][pixel] += W[co][k] X[k][pixel] on
+// v_mfma_f32_16x16x4_f32), different schedule, because here a tile has only 9..72 k-steps and the
+// per-tile fixed costs of the general kernel (re-staging the filter, cross-lane statistics, barriers with
+// nothing in flight) dominated the run time:
+//   * workgroups are PERSISTENT and walk a strided list of pixel tiles;
+//   * the whole packed filter (all taps, all input channels, all output channels) is staged into LDS ONCE;
+//   * the input tile of the NEXT pixel tile is fetched into registers (up to XMAX 16-byte loads per thread,
+//     twice that for the two-tensor gradient loads) before the MFMA phase of the current tile and written to
+//     LDS after it, so every CU keeps >= 64 KiB of HBM reads in flight while it computes and stores;
+//   * BatchNorm partial sums are accumulated in registers ACROSS tiles and reduced once per workgroup
+//     (one partial row per workgroup instead of one per tile): fixed order, no atomics.
+// A workgroup is 4 waves side by side along the pixels; every wave covers all (virtual) output channels
+// (WM blocks of 16) for its WN blocks of 16 pixels.  Kinds: KIND_GATHER (stride 1|2, dilation 1|2) and
+// KIND_TMERGED (transposed conv, merged-parity layout, see conv_mfma.hip).
+#include <stdlib.h>
+#include "conv_common.h"
+
+template <int CK>
+struct NarrowPitch {          // LDS floats per staged pixel: odd-ish pitch that spreads the 16 pixels of a block over the banks
+  static constexpr int value = CK == 32 ? 37 : CK + 1;
+};
+
+template <int MODE, int XMAX, int AMAX, int CK>
+__device__ __forceinline__ void narrow_write_x(const ConvArgs& a, float* xl, const float* cl, const float4 (&px)[XMAX],
+                                               const float4 (&pa)[AMAX], uint32_t okmask, int tid) {
+  constexpr int S = NarrowPitch<CK>::value, Q = CK / 4, STEP = 256 / Q;
+  const int q = tid % Q;
+  const int npix = a.IH * a.IW;
+  float4 k[5];
+  if (MODE != RCV_LOAD_PLAIN && MODE != RCV_LOAD_NCHW) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) k[j] = *reinterpret_cast<const float4*>(cl + j * a.Cin + 4 * q);
+  }
+#pragma unroll
+  for (int u = 0; u < XMAX; ++u) {
+    const int pix = tid / Q + u * STEP;
+    if (pix < npix) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((okmask >> u) & 1u) v = xform4<MODE>(px[u], pa[AMAX == XMAX ? u : 0], k);   // zero padding AFTER the transform
+      float* d = xl + pix * S + 4 * q;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+}
+
+template <int WM, int WN, int CK, int KIND, int XMAX, bool TWO>
+__global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
+  constexpr int NT = 256, WAVES = 4;
+  constexpr int COT = WM * 16;
+  constexpr int S = NarrowPitch<CK>::value;
+  constexpr int WS = COT + 16;
+  constexpr int Q = CK / 4;
+  constexpr int STEP = NT / Q;
+  constexpr int C4 = COT / 4;
+  constexpr int NTAPS = KIND == KIND_GATHER ? 9 : 4;
+  constexpr int NXT = KIND == KIND_GATHER ? 3 : 2;
+  constexpr int AMAX = TWO ? XMAX : 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;                        // [NTAPS][CK][WS]
+  float* xl = smem + a.wl_floats;          // [IH*IW][S]
+  float* cl = xl + a.xl_floats;            // [5][Cin]
+  float* red = cl + 5 * a.CinP + 16;       // [WAVES][2][COT]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int npix = a.IH * a.IW;
+
+  // ---- once per workgroup: load constants and the whole filter
+  if (a.in_c && a.in_mode != RCV_LOAD_PLAIN && a.in_mode != RCV_LOAD_NCHW)
+    for (int e = tid; e < 5 * a.Cin; e += NT) cl[e] = a.in_c[e];
+  for (int e = tid; e < NTAPS * CK * C4; e += NT) {
+    const int row = e / C4, c4 = e % C4;
+    const int j = row / CK, ck = row % CK;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (4 * c4 < a.CoutP && ck < a.CinP) v = ld4(a.w + ((size_t)(j * a.CinP + ck) * a.CoutP + 4 * c4));
+    *reinterpret_cast<float4*>(wl + row * WS + 4 * c4) = v;
+  }
+
+  // ---- prefetch registers
+  float4 px[XMAX], pa[AMAX];
+  uint32_t okmask = 0;
+  auto prefetch = [&](int t) {
+    const TileInfo ti = decode_tile<KIND>(a, t, COT);
+    okmask = 0;
+    if (a.in_mode == RCV_LOAD_NCHW) {
+#pragma unroll
+      for (int u = 0; u < XMAX; ++u) {
+        const int pix = tid + u * NT;
+        px[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (Q == 1 && pix < npix) {
+          const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
+          const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
+          if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+            okmask |= 1u << u;
+            const size_t plane = (size_t)a.H * a.W;
+            const size_t base = (size_t)ti.n * a.Cin * plane + (size_t)gy * a.W + gx;
+            if (0 < a.Cin) px[u].x = a.in[base];
+            if (1 < a.Cin) px[u].y = a.in[base + plane];
+            if (2 < a.Cin) px[u].z = a.in[base + 2 * plane];
+            if (3 < a.Cin) px[u].w = a.in[base + 3 * plane];
+          }
+        }
+      }
+    } else {
+      const int q = tid % Q;
+#pragma unroll
+      for (int u = 0; u < XMAX; ++u) {
+        const int pix = tid / Q + u * STEP;
+        px[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (TWO) pa[TWO ? u : 0] = px[u];
+        if (pix < npix) {
+          const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
+          const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
+          if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+            okmask |= 1u << u;
+            const size_t off = ((size_t)(ti.n * a.H + gy) * a.W + gx) * a.Cin + 4 * q;
+            px[u] = ld4(a.in + off);
+            if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
+          }
+        }
+      }
+    }
+  };
+
+  float s1[WM][4], s2[WM][4];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[m][r] = 0.f; s2[m][r] = 0.f; }
+
+  const int IS = KIND == KIND_GATHER ? a.stride : 1;
+  const int aoff = l4 * WS + l15;
+  int tile = blockIdx.x;
+  if (tile < a.total_tiles) prefetch(tile);
+
+  while (tile < a.total_tiles) {
+    const TileInfo ti = decode_tile<KIND>(a, tile, COT);
+    __syncthreads();                 // every wave is done reading the previous tile (and the filter is in place)
+    if (TWO) {
+      if (a.in_mode == RCV_LOAD_GRAD_ENC) narrow_write_x<RCV_LOAD_GRAD_ENC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid);
+      else narrow_write_x<RCV_LOAD_GRAD_DEC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid);
+    } else {
+      switch (a.in_mode) {
+        case RCV_LOAD_PLAIN: narrow_write_x<RCV_LOAD_PLAIN, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid); break;
+        case RCV_LOAD_AFFINE: narrow_write_x<RCV_LOAD_AFFINE, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid); break;
+        case RCV_LOAD_AFFINE_RELU: narrow_write_x<RCV_LOAD_AFFINE_RELU, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid); break;
+        default: narrow_write_x<RCV_LOAD_NCHW, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid); break;
+      }
+    }
+    const int ntile = tile + gridDim.x;
+    if (ntile < a.total_tiles) prefetch(ntile);      // in flight during the contraction and the stores below
+    __syncthreads();
+
+    // ---- contraction
+    int pixoff[WN];
+#pragma unroll
+    for (int b = 0; b < WN; ++b) {
+      const int p = (wave * WN + b) * 16 + l15;
+      int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
+      if (ty >= a.R) { ty = 0; tx = 0; }
+      pixoff[b] = ((ty * IS) * a.IW + tx * IS) * S + l4;
+    }
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int b = 0; b < WN; ++b) acc[m][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NTAPS; ++j) {
+      const int jy = j / NXT, jx = j % NXT;
+      const int dy = KIND == KIND_GATHER ? jy * a.dil : jy, dx = KIND == KIND_GATHER ? jx * a.dil : jx;
+      const float* wj = wl + j * CK * WS + aoff;
+      const float* xj = xl + (dy * a.IW + dx) * S;
+#pragma unroll
+      for (int kk = 0; kk < CK / 4; ++kk) {
+        float av[WM], bv[WN];
+#pragma unroll
+        for (int m = 0; m < WM; ++m) av[m] = wj[kk * 4 * WS + m * 16];
+#pragma unroll
+        for (int b = 0; b < WN; ++b) bv[b] = xj[pixoff[b] + kk * 4];
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+          for (int b = 0; b < WN; ++b)
+            acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[m][b], 0, 0, 0);
+      }
+    }
+
+    // ---- stores + statistics of this tile (statistics stay in registers)
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+      const int cov = m * 16 + 4 * l4;
+      int co = cov, py = 0, pxx = 0;
+      if (KIND == KIND_TMERGED) { const int ph = cov / a.Cout; co = cov - ph * a.Cout; py = ph >> 1; pxx = ph & 1; }
+      const bool co_ok = cov < a.CoutV;
+      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 e0 = bias, e1 = bias, mu = bias;
+      if (co_ok) {
+        if (a.flags & RCV_F_BIAS) bias = ld4(a.bias + co);
+        if (a.stats == RCV_STATS_BWD_DEC) { e0 = ld4(a.epi_c + co); e1 = ld4(a.epi_c + a.Cout + co); }
+        if (a.stats == RCV_STATS_BWD_DEC || a.stats == RCV_STATS_BWD_ENC) mu = ld4(a.epi_c + 2 * a.Cout + co);
+      }
+#pragma unroll
+      for (int b = 0; b < WN; ++b) {
+        const int p = (wave * WN + b) * 16 + l15;
+        const int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
+        int oy = ti.y0 + ty, ox = ti.x0 + tx;
+        bool ok = ty < a.R && co_ok;
+        if (KIND != KIND_GATHER) {
+          ok = ok && oy < a.H && ox < a.W;
+          oy = 2 * oy + py; ox = 2 * ox + pxx;
+        } else {
+          ok = ok && oy < a.Ho && ox < a.Wo;
+        }
+        if (!ok) continue;
+        const size_t off = ((size_t)(ti.n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+        float4 v = make_float4(acc[m][b][0] + bias.x, acc[m][b][1] + bias.y, acc[m][b][2] + bias.z, acc[m][b][3] + bias.w);
+        if (a.flags & RCV_F_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.flags & RCV_F_RESID) { const float4 rr = ld4(a.resid + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+        *reinterpret_cast<float4*>(a.out + off) = v;
+        if (a.stats == RCV_STATS_FWD) {
+          s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+          s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
+          s2[m][2] = fmaf(v.z, v.z, s2[m][2]); s2[m][3] = fmaf(v.w, v.w, s2[m][3]);
+        } else if (a.stats == RCV_STATS_BWD_ENC) {
+          const float4 e = ld4(a.epi_aux + off);
+          s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+          s2[m][0] = fmaf(v.x, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(v.y, e.y - mu.y, s2[m][1]);
+          s2[m][2] = fmaf(v.z, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(v.w, e.w - mu.w, s2[m][3]);
+        } else if (a.stats == RCV_STATS_BWD_DEC) {
+          const float4 e = ld4(a.epi_aux + off);
+          const float gx = fmaf(e.x, e0.x, e1.x) > 0.f ? v.x : 0.f;
+          const float gy = fmaf(e.y, e0.y, e1.y) > 0.f ? v.y : 0.f;
+          const float gz = fmaf(e.z, e0.z, e1.z) > 0.f ? v.z : 0.f;
+          const float gw = fmaf(e.w, e0.w, e1.w) > 0.f ? v.w : 0.f;
+          s1[m][0] += gx; s1[m][1] += gy; s1[m][2] += gz; s1[m][3] += gw;
+          s2[m][0] = fmaf(gx, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(gy, e.y - mu.y, s2[m][1]);
+          s2[m][2] = fmaf(gz, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(gw, e.w - mu.w, s2[m][3]);
+        }
+      }
+    }
+    tile = ntile;
+  }
+
+  // ---- one statistics row per workgroup
+  if (a.stats != RCV_STATS_NONE) {
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float u = s1[m][r], v = s2[m][r];
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) { u += __shfl_xor(u, sh); v += __shfl_xor(v, sh); }
+        s1[m][r] = u; s2[m][r] = v;
+      }
+    __syncthreads();
+    if (l15 == 0) {
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cl_ = m * 16 + 4 * l4 + r;
+          red[(wave * 2 + 0) * COT + cl_] = s1[m][r];
+          red[(wave * 2 + 1) * COT + cl_] = s2[m][r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * a.Cout; e += NT) {
+      const int which = e / a.Cout, co = e - which * a.Cout;
+      float u = 0.f;
+      for (int cv = co; cv < a.CoutV; cv += a.Cout) {   // merged layout: the four parity groups of a real channel
+#pragma unroll
+        for (int wn = 0; wn < WAVES; ++wn) u += red[(wn * 2 + which) * COT + cv];
+      }
+      a.part[((size_t)blockIdx.x * 2 + which) * a.Cout + co] = u;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------------
+static const int kNarrowXMAX = 8;
+static const int kNarrowWN = 5;
+
+bool convs_supported(const rcv_handle* h, const rcv_op* op, int kind, int CinP, int CoutV) {
+  (void)h; (void)op;
+  if (getenv("RCV_NO_NARROW")) return false;
+  if (kind == KIND_TPHASE) return false;
+  if (!(CinP == 4 || CinP == 8 || CinP == 16 || CinP == 32)) return false;
+  return round_up(CoutV, 16) <= 32;
+}
+
+int convs_make_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* pl) {
+  const int N = op->i[RCV_I_N], H = op->i[RCV_I_H], W = op->i[RCV_I_W];
+  const int Cin = op->i[RCV_I_CIN], Cout = op->i[RCV_I_COUT];
+  const int Ho = op->i[RCV_I_HO], Wo = op->i[RCV_I_WO];
+  const int s = op->i[RCV_I_STRIDE], d = op->i[RCV_I_DIL];
+  const int CinP = round_up(Cin, 4);
+  pl->kind = kind; pl->narrow = 1;
+  pl->CK = CinP;
+  pl->CoutV = kind == KIND_TMERGED ? 4 * Cout : Cout;
+  pl->CoutP = round_up(pl->CoutV, 16);
+  pl->WM = pl->CoutP / 16; pl->WN = kNarrowWN; pl->XMAX = kNarrowXMAX;
+  const int PIX = 64 * pl->WN;
+  const int Q = CinP / 4;
+  const int cap = (256 / Q) * pl->XMAX;
+  const int TH = kind == KIND_GATHER ? Ho : H, TW = kind == KIND_GATHER ? Wo : W;
+  // tile: rows x cols within PIX pixels and the prefetch capacity; minimise staged pixels + a small idle-lane penalty
+  double best = -1.0;
+  int ovR = 0, ovW = 0;
+  if (const char* ev = getenv("RCV_CONVS_TILE")) sscanf(ev, "%d,%d", &ovR, &ovW);
+  for (int nx = 1; nx <= TW; ++nx) {
+    const int wt = ceil_div(TW, nx);
+    if (wt > PIX) continue;
+    if (nx > 1 && wt < 8) break;
+    for (int r = PIX / wt < TH ? PIX / wt : TH; r >= 1; --r) {
+      int ih, iw;
+      tile_halo(kind, r, wt, s, d, &ih, &iw);
+      if (ih * iw > cap) continue;
+      if (ovR > 0 && !(r == ovR && wt == ovW)) continue;
+      const int rb = ceil_div(TH, ceil_div(TH, r));
+      tile_halo(kind, rb, wt, s, d, &ih, &iw);
+      const double tiles = (double)ceil_div(TW, wt) * ceil_div(TH, rb);
+      const double score = tiles * ((double)ih * iw + 0.25 * PIX + 64.0);
+      if (best < 0 || score < best) { best = score; pl->R = rb; pl->Wt = wt; }
+      break;
+    }
+  }
+  RCV_CHECK_ARG(best >= 0, "conv (narrow): no tile fits %dx%d", TH, TW);
+  pl->tiles_x = ceil_div(TW, pl->Wt); pl->tiles_y = ceil_div(TH, pl->R);
+  tile_halo(kind, pl->R, pl->Wt, s, d, &pl->IH, &pl->IW);
+  const int ntaps = kind == KIND_GATHER ? 9 : 4;
+  const int S = CinP == 32 ? 37 : CinP + 1;
+  pl->wl_floats = round_up(ntaps * CinP * (pl->CoutP + 16), 4);
+  pl->xl_floats = round_up(pl->IH * pl->IW * S, 4);
+  const size_t floats = (size_t)pl->wl_floats + pl->xl_floats + 5 * CinP + 16 + (size_t)4 * 2 * pl->CoutP;
+  pl->lds = floats * sizeof(float);
+  RCV_CHECK_ARG(pl->lds <= (size_t)h->max_lds, "conv (narrow): tile needs %zu B of LDS", pl->lds);
+  pl->n_co_tiles = 1; pl->n_phases = 1;
+  pl->total_tiles = N * pl->tiles_x * pl->tiles_y;
+  int occ = (int)((size_t)h->max_lds / pl->lds);
+  if (occ > 2) occ = 2;                       // launch bounds: 2 waves per SIMD
+  if (occ < 1) occ = 1;
+  if (const char* ev = getenv("RCV_CONVS_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4) occ = o; }
+  const int resident = h->num_cus * occ;
+  const int per = ceil_div(pl->total_tiles, resident);
+  pl->grid = ceil_div(pl->total_tiles, per);
+  return RCV_OK;
+}
+
+template <int WM, int CK, int KIND, bool TWO>
+static int convs_launch_inst(const ConvPlan& pl, const ConvArgs& a, hipStream_t s) {
+  auto kern = convs_mfma_kernel<WM, kNarrowWN, CK, KIND, kNarrowXMAX, TWO>;
+  static size_t configured = 0;
+  if (pl.lds > configured) {
+    RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
+    configured = pl.lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, s, a);
+  RCV_HIP(hipGetLastError());
+  return RCV_OK;
+}
+
+template <int WM, int CK, int KIND>
+static int convs_launch_two(const ConvPlan& pl, const ConvArgs& a, bool two, hipStream_t s) {
+  return two ? convs_launch_inst<WM, CK, KIND, true>(pl, a, s) : convs_launch_inst<WM, CK, KIND, false>(pl, a, s);
+}
+
+template <int WM, int KIND>
+static int convs_launch_ck(const ConvPlan& pl, const ConvArgs& a, bool two, hipStream_t s) {
+  switch (pl.CK) {
+    case 4: return convs_launch_two<WM, 4, KIND>(pl, a, two, s);
+    case 8: return convs_launch_two<WM, 8, KIND>(pl, a, two, s);
+    case 16: return convs_launch_two<WM, 16, KIND>(pl, a, two, s);
+    default: return convs_launch_two<WM, 32, KIND>(pl, a, two, s);
+  }
+}
+
+int convs_launch(const ConvPlan& pl, const ConvArgs& a, bool two, hipStream_t s) {
+  if (pl.kind == KIND_GATHER) return pl.WM == 1 ? convs_launch_ck<1, KIND_GATHER>(pl, a, two, s) : convs_launch_ck<2, KIND_GATHER>(pl, a, two, s);
+  return pl.WM == 1 ? convs_launch_ck<1, KIND_TMERGED>(pl, a, two, s) : convs_launch_ck<2, KIND_TMERGED>(pl, a, two, s);
+}

@@ -24,18 +24,31 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
   const rcv_pack_job jb = jobs[blockIdx.y];
   const int per_tap = jb.rows_pad * jb.cols_pad;
-  const int total = 9 * per_tap;
+  const int total = (jb.merged ? 4 : 9) * per_tap;
+  const int rows = jb.rows_from_d1 ? jb.D1 : jb.D0;
+  const int cols = jb.rows_from_d1 ? jb.D0 : jb.D1;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
     const int t = e / per_tap;
     const int rc = e - t * per_tap;
-    const int row = rc / jb.cols_pad, col = rc - row * jb.cols_pad;
-    const int rows = jb.rows_from_d1 ? jb.D1 : jb.D0;
-    const int cols = jb.rows_from_d1 ? jb.D0 : jb.D1;
+    const int row = rc / jb.cols_pad;
+    int col = rc - row * jb.cols_pad;
     float v = 0.f;
-    if (row < rows && col < cols) {
+    int ts = jb.flip ? 8 - t : t;
+    bool ok = row < rows && col < cols;
+    if (jb.merged) {
+      // virtual column = parity*cols + col; tap t = (dy,dx) of the 2x2 input window.
+      // output row 2y+py takes input row y+dy through filter row ky: py=0: (dy=0,ky=1); py=1: (dy=0,ky=2),(dy=1,ky=0)
+      const int ph = col / cols;
+      col -= ph * cols;
+      const int py = ph >> 1, px = ph & 1, dy = t >> 1, dx = t & 1;
+      const int ky = py ? (dy ? 0 : 2) : (dy ? -1 : 1);
+      const int kx = px ? (dx ? 0 : 2) : (dx ? -1 : 1);
+      ok = row < rows && ph < 4 && ky >= 0 && kx >= 0;
+      ts = ky * 3 + kx;
+    }
+    if (ok) {
       const int d0 = jb.rows_from_d1 ? col : row;
       const int d1 = jb.rows_from_d1 ? row : col;
-      const int ts = jb.flip ? 8 - t : t;
       v = jb.src[((size_t)d0 * jb.D1 + d1) * 9 + ts];
     }
     jb.dst[e] = v;
@@ -74,7 +87,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int n_part, i
     const float sc = gamma[c] * istd;
     consts[0 * C + c] = sc;
     consts[1 * C + c] = beta[c] - (float)mean * sc;
-    consts[2 * C + c] = 0.f; consts[3 * C + c] = 0.f; consts[4 * C + c] = 0.f;
+    consts[2 * C + c] = (float)mean;          // row 2: batch mean (the backward sums are taken about it)
+    consts[3 * C + c] = 0.f; consts[4 * C + c] = 0.f;
     save_mean[c] = (float)mean;
     save_istd[c] = istd;
     if (training && running_mean) {
@@ -110,8 +124,9 @@ __global__ void bn_bwd_kernel(const float* __restrict__ part, int n_part, int C,
   }
   block_sum2_d(s1, s2);
   if (threadIdx.x == 0) {
+    // s2 arrives centred: sum g*(r - mean) (accumulated about the batch mean to avoid cancellation)
     const double mean = save_mean[c], istd = save_istd[c];
-    const double sgx = istd * (s2 - mean * s1);
+    const double sgx = istd * s2;
     const double A = (double)gamma[c] * istd;
     const double Cc = -A * istd * sgx / count;
     const double B = -A * s1 / count - Cc * mean;
@@ -234,7 +249,7 @@ __global__ void cls_bwd_kernel(const float* __restrict__ up, const float* __rest
           const int k = 4 * q + j;
           const float gm = fmaf(tv[j], tc[k], tc[CIN + k]) > 0.f ? d[k] : 0.f;
           s1[k] += gm;
-          s2[k] = fmaf(gm, tv[j], s2[k]);
+          s2[k] = fmaf(gm, tv[j] - tc[2 * CIN + k], s2[k]);
         }
       }
     }
@@ -405,7 +420,8 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dp, const float* __res
   const size_t total = (size_t)N * Ho * Wo * C4;
   const int q = threadIdx.x % C4;
   float4 s = make_float4(1.f, 1.f, 1.f, 1.f), h = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (MODE != RCV_LOAD_PLAIN) { s = sld4(cst + 4 * q); h = sld4(cst + C + 4 * q); }
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE != RCV_LOAD_PLAIN) { s = sld4(cst + 4 * q); h = sld4(cst + C + 4 * q); if (stats != RCV_STATS_NONE) mu = sld4(cst + 2 * C + 4 * q); }
   float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     size_t pp = e / C4;
@@ -432,7 +448,8 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dp, const float* __res
       if (resid) { const float4 rr = sld4(resid + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
       sst4(dy + off, v);
       a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
-      a2.x = fmaf(v.x, rv[j].x, a2.x); a2.y = fmaf(v.y, rv[j].y, a2.y); a2.z = fmaf(v.z, rv[j].z, a2.z); a2.w = fmaf(v.w, rv[j].w, a2.w);
+      a2.x = fmaf(v.x, rv[j].x - mu.x, a2.x); a2.y = fmaf(v.y, rv[j].y - mu.y, a2.y);
+      a2.z = fmaf(v.z, rv[j].z - mu.z, a2.z); a2.w = fmaf(v.w, rv[j].w - mu.w, a2.w);
     }
   }
   if (stats != RCV_STATS_NONE) {
@@ -518,6 +535,7 @@ __global__ void bwd_stats_kernel(const float* __restrict__ g, const float* __res
   const int q = threadIdx.x % C4;
   float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
   if (stats == RCV_STATS_BWD_DEC) { c0 = sld4(ec + 4 * q); c1 = sld4(ec + C + 4 * q); }
+  const float4 mu = sld4(ec + 2 * C + 4 * q);
   float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
     float4 v = sld4(g + e * 4);
@@ -528,7 +546,8 @@ __global__ void bwd_stats_kernel(const float* __restrict__ g, const float* __res
       v.z = fmaf(x.z, c0.z, c1.z) > 0.f ? v.z : 0.f; v.w = fmaf(x.w, c0.w, c1.w) > 0.f ? v.w : 0.f;
     }
     a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w;
-    a2.x = fmaf(v.x, x.x, a2.x); a2.y = fmaf(v.y, x.y, a2.y); a2.z = fmaf(v.z, x.z, a2.z); a2.w = fmaf(v.w, x.w, a2.w);
+    a2.x = fmaf(v.x, x.x - mu.x, a2.x); a2.y = fmaf(v.y, x.y - mu.y, a2.y);
+    a2.z = fmaf(v.z, x.z - mu.z, a2.z); a2.w = fmaf(v.w, x.w - mu.w, a2.w);
   }
   sh4[threadIdx.x] = a1;
   sh4[blockDim.x + threadIdx.x] = a2;
@@ -766,7 +785,7 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       const int stats = op->i[RCV_I_STATS];
       if (query) { query->n_part = g; query->part_bytes = (size_t)g * 2 * Cout * sizeof(float); return RCV_OK; }
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_EPI_AUX] && op->p[RCV_P_OUT] && op->p[RCV_P_PART], "bwd_stats: null operand");
-      RCV_CHECK_ARG(stats != RCV_STATS_BWD_DEC || op->p[RCV_P_EPI_C], "bwd_stats: decoder constants missing");
+      RCV_CHECK_ARG(op->p[RCV_P_EPI_C], "bwd_stats: constants (scale, shift, mean) missing");
       RCV_CHECK_ARG(op->i[RCV_I_NPART] == g, "bwd_stats: workspace rows %d != %d", op->i[RCV_I_NPART], g);
       hipLaunchKernelGGL(bwd_stats_kernel, dim3(g), dim3(256), 2 * 256 * sizeof(float4), s, (const float*)op->p[RCV_P_IN],
                          (const float*)op->p[RCV_P_EPI_AUX], (const float*)op->p[RCV_P_EPI_C], (float*)op->p[RCV_P_OUT],

@@ -76,19 +76,37 @@ __device__ __forceinline__ float4 stage_tile(const float* src, const float* aux,
   }
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   const int npix = rows * cols;
-  for (int pix = tid / Q; pix < npix; pix += NT / Q) {
-    const int iy = fd_div(pix, fdcols), ix = pix - iy * cols;
-    const int gy = gy0 + iy, gx = gx0 + ix;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ch_ok && iy < rows_valid && ix < cols_valid && (unsigned)gy < (unsigned)Himg && (unsigned)gx < (unsigned)Wimg) {
-      const size_t off = ((size_t)(n * Himg + gy) * Wimg + gx) * C + ch;
-      const float4 x = wld4(src + off);
-      float4 a = x;
-      if (MODE == RCV_LOAD_GRAD_ENC || MODE == RCV_LOAD_GRAD_DEC) a = wld4(aux + off);
-      v = wxform4<MODE>(x, a, k);
-      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+  constexpr int UNR = 4;            // independent loads in flight per thread (see conv_mfma.hip)
+  constexpr int STEP = NT / Q;
+  for (int pix0 = tid / Q; pix0 < npix; pix0 += UNR * STEP) {
+    float4 x[UNR], a[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int pix = pix0 + u * STEP;
+      const int iy = fd_div(pix, fdcols), ix = pix - iy * cols;
+      const int gy = gy0 + iy, gx = gx0 + ix;
+      ok[u] = pix < npix && ch_ok && iy < rows_valid && ix < cols_valid && (unsigned)gy < (unsigned)Himg && (unsigned)gx < (unsigned)Wimg;
+      x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      a[u] = x[u];
+      if (ok[u]) {
+        const size_t off = ((size_t)(n * Himg + gy) * Wimg + gx) * C + ch;
+        x[u] = wld4(src + off);
+        if (MODE == RCV_LOAD_GRAD_ENC || MODE == RCV_LOAD_GRAD_DEC) a[u] = wld4(aux + off);
+      }
     }
-    *reinterpret_cast<float4*>(dst + pix * SD + 4 * q) = v;
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int pix = pix0 + u * STEP;
+      if (pix < npix) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok[u]) {
+          v = wxform4<MODE>(x[u], a[u], k);
+          sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        *reinterpret_cast<float4*>(dst + pix * SD + 4 * q) = v;
+      }
+    }
   }
   return sum;
 }
@@ -261,12 +279,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int CBP, int CAP) {
   // 64 consecutive partial-layout elements x 4 split groups per workgroup; every thread keeps 4 loads in
   // flight; the order of additions is a fixed function of (nsplit) => bitwise reproducible.
-  __shared__ float sh[4][64];
+  __shared__ double sh[4][64];
   const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int totalP = 9 * CBP * CAP;
   const int e = blockIdx.x * 64 + el;
   const size_t stride = (size_t)totalP;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;     // double: bias / BN-adjacent filters are cancellation-heavy sums
   const float* src = nullptr;
   size_t st = 0;
   if (e < totalP) { src = part + e; st = stride; }
@@ -274,15 +292,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   if (src) {
     int sidx = grp;
     for (; sidx + 12 < nsplit; sidx += 16) {
-      a0 += src[(size_t)sidx * st]; a1 += src[(size_t)(sidx + 4) * st];
-      a2 += src[(size_t)(sidx + 8) * st]; a3 += src[(size_t)(sidx + 12) * st];
+      a0 += (double)src[(size_t)sidx * st]; a1 += (double)src[(size_t)(sidx + 4) * st];
+      a2 += (double)src[(size_t)(sidx + 8) * st]; a3 += (double)src[(size_t)(sidx + 12) * st];
     }
-    for (; sidx < nsplit; sidx += 4) a0 += src[(size_t)sidx * st];
+    for (; sidx < nsplit; sidx += 4) a0 += (double)src[(size_t)sidx * st];
   }
   sh[grp][el] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (grp == 0 && src) {
-    const float u = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
+    const float u = (float)((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]));
     if (e < totalP) {
       const int ca = e % CAP;
       const int cb = (e / CAP) % CBP;

@@ -26,6 +26,7 @@ from . import _lib as L
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+MERGED_TCONV_MAX_COUT = 16      # transposed convs with at most this many output channels use the merged-parity kernel
 
 
 def _ptr(t: Optional[torch.Tensor]) -> int:
@@ -198,16 +199,21 @@ class Engine:
         # ---- weight packing table (all layers, one launch per forward) ----
         jobs: List[L.RcvPackJob] = []
 
-        def add_pack(param, D0, D1, rows_from_d1, flip):
+        def add_pack(param, D0, D1, rows_from_d1, flip, merged=False):
             rows = D1 if rows_from_d1 else D0
             cols = D0 if rows_from_d1 else D1
-            rp, cp = _round_up(rows, 4), _round_up(cols, 16)
-            dst = self._zeros(plan, 9 * rp * cp)
+            rp, cp = _round_up(rows, 4), _round_up(cols * (4 if merged else 1), 16)
+            dst = self._zeros(plan, (4 if merged else 9) * rp * cp)
             j = L.RcvPackJob()
             j.src, j.dst, j.D0, j.D1 = param.data_ptr(), dst.data_ptr(), D0, D1
             j.rows_from_d1, j.flip, j.rows_pad, j.cols_pad = int(rows_from_d1), int(flip), rp, cp
+            j.merged = int(merged)
             jobs.append(j)
             return dst
+
+        def use_merged(cout: int) -> bool:
+            # narrow transposed convs are HBM bound: one pass writing whole output rows beats four parity passes
+            return cout <= MERGED_TCONV_MAX_COUT
 
         bn_finalize_flags = L.F_TRAINING if training else 0
 
@@ -275,11 +281,11 @@ class Engine:
                 if Cin != src.C:
                     raise L.RcvError("up node %d: input has %d channels, weight expects %d" % (node.idx, src.C, Cin))
                 Ho, Wo = 2 * src.H, 2 * src.W
-                node.t["wp"] = add_pack(w, Cin, Cout, False, False)
+                node.t["wp"] = add_pack(w, Cin, Cout, False, False, merged=use_merged(Cout))
                 t = self._alloc(plan, N, Ho, Wo, Cout)
                 bn_tensors(node, Cout)
                 op = L.make_op(L.OP_TCONV, (L.F_BIAS if b is not None else 0), n=N, h=src.H, w=src.W, cin=Cin, cout=Cout,
-                               ho=Ho, wo=Wo, stride=2, dil=1, inmode=src.load_mode, p_in_c=_ptr(src.consts),
+                               ho=Ho, wo=Wo, stride=2, dil=1, aux0=int(use_merged(Cout)), inmode=src.load_mode, p_in_c=_ptr(src.consts),
                                p_w=node.t["wp"].data_ptr(), p_bias=_ptr(b), p_out=t.data_ptr())
                 op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
                 emit_bn_forward(node, bn, op, Cout, Ho, Wo)
@@ -346,6 +352,7 @@ class Engine:
                 elif prod.op == "conv":
                     writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_ENC
                     writer_op.p[L.RCV_P_EPI_AUX] = v.buf.data_ptr()
+                    writer_op.p[L.RCV_P_EPI_C] = prod.t["consts"].data_ptr()     # row 2 = batch mean
                 elif prod.op == "up":
                     writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_DEC
                     writer_op.p[L.RCV_P_EPI_AUX] = prod.t["t"].data_ptr()
@@ -462,8 +469,9 @@ class Engine:
                         else:
                             if src.H != 2 * out.H or src.W != 2 * out.W:
                                 raise L.RcvError("stride-2 conv backward needs even input dims (got %dx%d)" % (src.H, src.W))
-                            node.t["wd"] = add_pack(w, Cout, Cin, False, False)
+                            node.t["wd"] = add_pack(w, Cout, Cin, False, False, merged=use_merged(Cin))
                             dop = L.make_op(L.OP_TCONV, 0, n=N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=2, dil=1,
+                                            aux0=int(use_merged(Cin)),
                                             inmode=L.LOAD_GRAD_ENC, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
                                             p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
                         grad_target(src, dop, src.H, src.W)
@@ -475,7 +483,7 @@ class Engine:
         host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
         dev_table = host.to(self.device)
         plan.keep.append(dev_table)
-        max_elems = max(9 * j.rows_pad * j.cols_pad for j in jobs)
+        max_elems = max((4 if j.merged else 9) * j.rows_pad * j.cols_pad for j in jobs)
         pack_op = L.make_op(L.OP_PACK, 0, count=len(jobs), aux0=max_elems, p_in=dev_table.data_ptr())
         head = [pack_op] + pre
         for slots in plan.input_slots:

@@ -132,7 +132,10 @@ def test_step_vs_golden_big(net_kats, net_meta, tag):
         # sums (conv biases, BN affine of wide layers) the fp32 reference is itself up to ~2e-3 from the exact value
         n32, n64 = m["grad_summary"][k][2], m["fp64"]["grad_summary"][k][2]
         got = float(g.double().norm())
-        assert abs(got - n32) <= 1e-3 * n32 + 1e-7 or abs(got - n64) <= 1e-3 * n64 + 1e-7, (k, got, n32, n64)
+        # per-channel parameters (BN affine, conv bias) are sums over ~1e5..1e7 pixels that cancel to ~1e-4 of their
+        # terms: 1e-2 there (the fp32 reference moves by ~1e-3 on them), 1e-3 for the filters
+        tol = 1e-2 if (k.endswith("bn.weight") or k.endswith("bn.bias") or k.endswith("conv.bias")) else 1e-3
+        assert abs(got - n32) <= tol * n32 + 1e-7 or abs(got - n64) <= tol * n64 + 1e-7, (k, got, n32, n64)
 
 
 def test_step_vs_oracle_on_box():
