@@ -8,12 +8,19 @@
 //   convT layer (model.py:186):  G = dt, the gradient at the 2x output (zero padded), stride 2,
 //                                P = layer input; dW is [Cin][Cout][3][3] -- the same index formula.
 //
-// GEMM mapping per tap:  D[cb][ca] += A[cb][k] * B[k][ca],  k = pixel (4 consecutive pixels of a tile
-// row per MFMA).  Both tiles sit in LDS channel-contiguous ([pixel][C + pad]); the pads make the two
-// pixels of a 32-lane group land on disjoint banks.  A wave keeps all nine taps of its
-// (WM x WN) x 16x16 channel tile in registers (9*WM*WN*4 VGPRs) and walks pixel tiles; workgroups
-// write partial filters [split][tap][cb][ca] that RCV_OP_WGRAD_REDUCE sums in a fixed order (no
+// GEMM mapping:  D[cb][n] += A[cb][k] * B[k][n],  k = pixel (4 consecutive pixels of a tile row per MFMA).
+//   regular mode (>= 16 gathered channels): n = ca, one accumulator set per tap; a wave keeps all nine taps of
+//     its (WM x WN) x 16x16 channel tile in registers (9*WM*WN*4 VGPRs);
+//   folded mode (<= 8 gathered channels: the image, the 8-channel layers): n = (tap, ca) flattened, so the nine
+//     taps of a 3- or 8-channel operand fill 2 or 5 MFMA column blocks instead of 9 mostly empty ones.
+// Both tiles sit in LDS ([pixel][C + pad]); B is read through a per-lane offset table.
+//
+// Schedule: workgroups are persistent over pixel tiles (a pixel split per workgroup); per tile both operands are
+// staged global -> registers -> LDS with the load transform applied (4 independent 16-byte loads per thread in
+// flight), then the MFMA phase runs; two workgroups per CU overlap one's staging with the other's MFMAs.
+// Workgroups write partial filters [split][tap][cb][ca] that RCV_OP_WGRAD_REDUCE sums in a fixed order (no
 // float atomics => bitwise reproducible gradients).
+#include <stdlib.h>
 #include "rcv_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -28,7 +35,7 @@ struct WgradArgs {
   int stride, dil;
   int R, Wt, Wt4, tiles_x, tiles_y, ntiles, IH, IW, SP, SG;
   int nsplit;
-  int pl_floats;      // floats of the P tile (G tile follows)
+  int pl_floats, gl_floats;      // LDS carve: P tile, G tile (then the load constants)
   FastDiv fdWt4, fdIW;
 };
 
@@ -37,7 +44,7 @@ __device__ __forceinline__ float4 wld4(const float* p) { return *reinterpret_cas
 template <int MODE>
 __device__ __forceinline__ float4 wxform4(float4 x, float4 a, const float4 (&k)[5]) {
   float4 v;
-  if (MODE == RCV_LOAD_PLAIN) {
+  if (MODE == RCV_LOAD_PLAIN || MODE == RCV_LOAD_NCHW) {
     v = x;
   } else if (MODE == RCV_LOAD_AFFINE) {
     v.x = fmaf(x.x, k[0].x, k[1].x); v.y = fmaf(x.y, k[0].y, k[1].y);
@@ -59,76 +66,28 @@ __device__ __forceinline__ float4 wxform4(float4 x, float4 a, const float4 (&k)[
   return v;
 }
 
-// Stage a [rows x cols] pixel window of an NHWC tensor (C channels, tile channels [c0, c0+CT)) into
-// dst[pixel][SD]; out-of-image pixels and channels >= C are zero (AFTER the transform).
-template <int MODE, int CT, int NT>
-__device__ __forceinline__ float4 stage_tile(const float* src, const float* aux, const float* cst, int C, int Himg, int Wimg,
-                                             int n, int gy0, int gx0, int rows_valid, int cols_valid, int rows, int cols,
-                                             FastDiv fdcols, int c0, float* dst, int SD, int tid) {
-  constexpr int Q = CT / 4;
-  const int q = tid % Q;
-  const int ch = c0 + 4 * q;
-  const bool ch_ok = ch < C;
-  float4 k[5];
-  if (MODE != RCV_LOAD_PLAIN && ch_ok) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j) k[j] = wld4(cst + (size_t)j * C + ch);
-  }
-  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int npix = rows * cols;
-  constexpr int UNR = 4;            // independent loads in flight per thread (see conv_mfma.hip)
-  constexpr int STEP = NT / Q;
-  for (int pix0 = tid / Q; pix0 < npix; pix0 += UNR * STEP) {
-    float4 x[UNR], a[UNR];
-    bool ok[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int pix = pix0 + u * STEP;
-      const int iy = fd_div(pix, fdcols), ix = pix - iy * cols;
-      const int gy = gy0 + iy, gx = gx0 + ix;
-      ok[u] = pix < npix && ch_ok && iy < rows_valid && ix < cols_valid && (unsigned)gy < (unsigned)Himg && (unsigned)gx < (unsigned)Wimg;
-      x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      a[u] = x[u];
-      if (ok[u]) {
-        const size_t off = ((size_t)(n * Himg + gy) * Wimg + gx) * C + ch;
-        x[u] = wld4(src + off);
-        if (MODE == RCV_LOAD_GRAD_ENC || MODE == RCV_LOAD_GRAD_DEC) a[u] = wld4(aux + off);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int pix = pix0 + u * STEP;
-      if (pix < npix) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok[u]) {
-          v = wxform4<MODE>(x[u], a[u], k);
-          sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-        }
-        *reinterpret_cast<float4*>(dst + pix * SD + 4 * q) = v;
-      }
-    }
-  }
-  return sum;
-}
-
-template <int CT, int NT>
-__device__ __forceinline__ float4 stage_dispatch(int mode, const float* src, const float* aux, const float* cst, int C, int Himg,
-                                                 int Wimg, int n, int gy0, int gx0, int rows_valid, int cols_valid, int rows,
-                                                 int cols, FastDiv fdcols, int c0, float* dst, int SD, int tid) {
+__device__ __forceinline__ float4 wxform_rt(int mode, float4 x, float4 a, const float4 (&k)[5]) {
   switch (mode) {
-    case RCV_LOAD_PLAIN: return stage_tile<RCV_LOAD_PLAIN, CT, NT>(src, aux, cst, C, Himg, Wimg, n, gy0, gx0, rows_valid, cols_valid, rows, cols, fdcols, c0, dst, SD, tid);
-    case RCV_LOAD_AFFINE: return stage_tile<RCV_LOAD_AFFINE, CT, NT>(src, aux, cst, C, Himg, Wimg, n, gy0, gx0, rows_valid, cols_valid, rows, cols, fdcols, c0, dst, SD, tid);
-    case RCV_LOAD_AFFINE_RELU: return stage_tile<RCV_LOAD_AFFINE_RELU, CT, NT>(src, aux, cst, C, Himg, Wimg, n, gy0, gx0, rows_valid, cols_valid, rows, cols, fdcols, c0, dst, SD, tid);
-    case RCV_LOAD_GRAD_ENC: return stage_tile<RCV_LOAD_GRAD_ENC, CT, NT>(src, aux, cst, C, Himg, Wimg, n, gy0, gx0, rows_valid, cols_valid, rows, cols, fdcols, c0, dst, SD, tid);
-    default: return stage_tile<RCV_LOAD_GRAD_DEC, CT, NT>(src, aux, cst, C, Himg, Wimg, n, gy0, gx0, rows_valid, cols_valid, rows, cols, fdcols, c0, dst, SD, tid);
+    case RCV_LOAD_PLAIN: case RCV_LOAD_NCHW: return x;
+    case RCV_LOAD_AFFINE: return wxform4<RCV_LOAD_AFFINE>(x, a, k);
+    case RCV_LOAD_AFFINE_RELU: return wxform4<RCV_LOAD_AFFINE_RELU>(x, a, k);
+    case RCV_LOAD_GRAD_ENC: return wxform4<RCV_LOAD_GRAD_ENC>(x, a, k);
+    default: return wxform4<RCV_LOAD_GRAD_DEC>(x, a, k);
   }
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K>
+// NBF == 0: regular mode (WN column blocks of 16 gathered channels, 9 taps each)
+// NBF  > 0: folded mode (WN must be 1): NBF column blocks over n = tap*CA + ca
+// GTWO: the gathered operand is a two-tensor gradient load (convT layer); otherwise the pointwise one may be.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, int XP, int XG, bool GTWO>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_kernel(const WgradArgs a) {
   constexpr int NT = WAVES_M * WAVES_N * WAVES_K * 64;
   constexpr int CBT = WM * WAVES_M * 16;
   constexpr int CAT = WN * WAVES_N * 16;
+  constexpr bool FOLD = NBF > 0;
+  constexpr int NACC = FOLD ? NBF : 9 * WN;
+  constexpr int QP = CBT / 4;
+  constexpr int STEPP = NT / QP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* pl = smem;
   float* gl = smem + a.pl_floats;
@@ -139,54 +98,170 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
   const int wave_m = wave / (WAVES_K * WAVES_N);
   const int l15 = lane & 15, l4 = lane >> 4;
 
-  const int n_ca_tiles = (a.CAP + CAT - 1) / CAT;
+  const int n_ca_tiles = FOLD ? 1 : (a.CAP + CAT - 1) / CAT;
   const int cb_tile = blockIdx.y / n_ca_tiles, ca_tile = blockIdx.y % n_ca_tiles;
   const int cb0 = cb_tile * CBT, ca0 = ca_tile * CAT;
-
-  f32x4 acc[9][WM][WN];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int m = 0; m < WM; ++m)
-#pragma unroll
-      for (int nn = 0; nn < WN; ++nn) acc[t][m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-
   const int s = a.stride, d = a.dil;
-  const int ksteps = a.R * a.Wt4 / 4;
-  const int a_lane = l4 * a.SP + (wave_m * WM) * 16 + l15;
-  const int g_lane = (l4 * s) * a.SG + (wave_n * WN) * 16 + l15;
+  const int QG = FOLD ? (a.CA + 3) / 4 : CAT / 4;        // 16-byte quads per staged gathered pixel
+  const int STEPG = NT / QG;
+  const int np_pix = a.R * a.Wt4, ng_pix = a.IH * a.IW;
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.nsplit) {
+
+  // ---------------- staging: global -> (load transform) -> LDS, 4 independent 16-byte loads per thread in flight ----------------
+  const bool p_two = a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC;
+  const bool g_two = a.g_mode == RCV_LOAD_GRAD_ENC || a.g_mode == RCV_LOAD_GRAD_DEC;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int UNR = 4;
+  auto stage = [&](int tile) {
     int t = tile;
     const int tx_i = t % a.tiles_x;
     t /= a.tiles_x;
     const int ty_i = t % a.tiles_y;
     const int n = t / a.tiles_y;
     const int y0 = ty_i * a.R, x0 = tx_i * a.Wt;
-    __syncthreads();
-    // P tile: R x Wt4 pixels (columns >= Wt and rows/cols outside the plane are zero)
-    const float4 bs = stage_dispatch<CBT, NT>(a.p_mode, a.p, a.p_aux, a.p_c, a.CB, a.Hp, a.Wp, n, y0, x0, a.R, a.Wt, a.R, a.Wt4,
-                                              a.fdWt4, cb0, pl, a.SP, tid);
-    bsum.x += bs.x; bsum.y += bs.y; bsum.z += bs.z; bsum.w += bs.w;
-    // G tile: IH x IW pixels around it
-    if (a.g_mode == RCV_LOAD_NCHW) {
-      const int npix = a.IH * a.IW;
-      for (int pix = tid; pix < npix; pix += NT) {
-        const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
-        const int gy = y0 * s - d + iy, gx = x0 * s - d + ix;
-        const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    {   // pointwise tile: R x Wt4 pixels (columns >= Wt and anything outside the plane are zero)
+      const int q = tid % QP;
+      const int ch = cb0 + 4 * q;
+      const bool ch_ok = ch < a.CB;
+      float4 k[5];
+      if (a.p_mode != RCV_LOAD_PLAIN && ch_ok) {
 #pragma unroll
-        for (int j = 0; j < CAT; ++j) {
-          float v = 0.f;
-          if (ok && j < 4 && ca0 + j < a.CA) v = a.g[((size_t)(n * a.CA + ca0 + j) * a.H + gy) * a.W + gx];
-          gl[pix * a.SG + j] = v;
+        for (int j = 0; j < 5; ++j) k[j] = wld4(a.p_c + (size_t)j * a.CB + ch);
+      }
+      for (int pix0 = tid / QP; pix0 < np_pix; pix0 += UNR * STEPP) {
+        float4 x[UNR], ax[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int pix = pix0 + u * STEPP;
+          const int iy = fd_div(pix, a.fdWt4), ix = pix - iy * a.Wt4;
+          const int gy = y0 + iy, gx = x0 + ix;
+          ok[u] = pix < np_pix && ch_ok && ix < a.Wt && gy < a.Hp && gx < a.Wp;
+          x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          ax[u] = x[u];
+          if (ok[u]) {
+            const size_t off = ((size_t)(n * a.Hp + gy) * a.Wp + gx) * a.CB + ch;
+            x[u] = wld4(a.p + off);
+            if (p_two) ax[u] = wld4(a.p_aux + off);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int pix = pix0 + u * STEPP;
+          if (pix < np_pix) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[u]) {
+              v = wxform_rt(a.p_mode, x[u], ax[u], k);
+              bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+            }
+            *reinterpret_cast<float4*>(pl + pix * a.SP + 4 * q) = v;
+          }
+        }
+      }
+    }
+    if (a.g_mode == RCV_LOAD_NCHW) {   // gathered tile from the NCHW image: one pixel (<= 4 planes) per thread
+      for (int pix0 = tid; pix0 < ng_pix; pix0 += UNR * NT) {
+        float4 x[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int pix = pix0 + u * NT;
+          x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
+          const int gy = y0 * s - d + iy, gx = x0 * s - d + ix;
+          if (pix < ng_pix && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+            const size_t plane = (size_t)a.H * a.W;
+            const size_t base = (size_t)n * a.CA * plane + (size_t)gy * a.W + gx;
+            if (0 < a.CA) x[u].x = a.g[base];
+            if (1 < a.CA) x[u].y = a.g[base + plane];
+            if (2 < a.CA) x[u].z = a.g[base + 2 * plane];
+            if (3 < a.CA) x[u].w = a.g[base + 3 * plane];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int pix = pix0 + u * NT;
+          if (pix < ng_pix) {
+            float* dst = gl + pix * a.SG;
+            dst[0] = x[u].x; dst[1] = x[u].y; dst[2] = x[u].z; dst[3] = x[u].w;
+            if (!FOLD) {
+#pragma unroll
+              for (int j = 4; j < CAT; ++j) dst[j] = 0.f;
+            }
+          }
         }
       }
     } else {
-      stage_dispatch<CAT, NT>(a.g_mode, a.g, a.g_aux, a.g_c, a.CA, a.H, a.W, n, y0 * s - d, x0 * s - d, a.IH, a.IW, a.IH, a.IW,
-                              a.fdIW, ca0, gl, a.SG, tid);
+      const int q = tid % QG;
+      const int ch = ca0 + 4 * q;
+      const bool ch_ok = ch < a.CA;
+      float4 k[5];
+      if (a.g_mode != RCV_LOAD_PLAIN && ch_ok) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) k[j] = wld4(a.g_c + (size_t)j * a.CA + ch);
+      }
+      for (int pix0 = tid / QG; pix0 < ng_pix; pix0 += UNR * STEPG) {
+        float4 x[UNR], ax[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int pix = pix0 + u * STEPG;
+          const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
+          const int gy = y0 * s - d + iy, gx = x0 * s - d + ix;
+          ok[u] = pix < ng_pix && ch_ok && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+          x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          ax[u] = x[u];
+          if (ok[u]) {
+            const size_t off = ((size_t)(n * a.H + gy) * a.W + gx) * a.CA + ch;
+            x[u] = wld4(a.g + off);
+            if (g_two) ax[u] = wld4(a.g_aux + off);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int pix = pix0 + u * STEPG;
+          if (pix < ng_pix) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok[u]) v = wxform_rt(a.g_mode, x[u], ax[u], k);
+            float* dst = gl + pix * a.SG + 4 * q;
+            if (FOLD) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+            else *reinterpret_cast<float4*>(dst) = v;
+          }
+        }
+      }
     }
+  };
+
+  // ---------------- accumulators and lane offsets ----------------
+  f32x4 acc[NACC][WM];
+#pragma unroll
+  for (int t = 0; t < NACC; ++t)
+#pragma unroll
+    for (int m = 0; m < WM; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int loff[NACC];
+  if (FOLD) {
+#pragma unroll
+    for (int nb = 0; nb < NACC; ++nb) {
+      int nn = nb * 16 + l15;
+      if (nn >= 9 * a.CA) nn = 0;                       // columns beyond 9*CA are discarded at the end
+      const int tap = nn / a.CA, ca = nn - tap * a.CA;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      loff[nb] = ((ky * d) * a.IW + kx * d) * a.SG + ca + (l4 * s) * a.SG;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int nn = 0; nn < WN; ++nn) {
+        const int ky = t / 3, kx = t - ky * 3;
+        loff[t * WN + nn] = ((ky * d) * a.IW + kx * d) * a.SG + (l4 * s) * a.SG + (wave_n * WN + nn) * 16 + l15;
+      }
+  }
+  const int ksteps = np_pix / 4;
+  const int a_lane = l4 * a.SP + (wave_m * WM) * 16 + l15;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.nsplit) {
+    __syncthreads();                  // previous MFMA phase is done with the tiles (and the constants are in place)
+    stage(tile);
     __syncthreads();
     for (int j = wave_k; j < ksteps; j += WAVES_K) {
       const int p0 = 4 * j;
@@ -194,79 +269,71 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
       float av[WM];
 #pragma unroll
       for (int m = 0; m < WM; ++m) av[m] = pl[p0 * a.SP + a_lane + m * 16];
-      const float* gj = gl + ((ty * s) * a.IW + tx * s) * a.SG + g_lane;
+      const float* gj = gl + ((ty * s) * a.IW + tx * s) * a.SG;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int t = 0; t < NACC; ++t) {
+        const float bv = gj[loff[t]];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const float* gt = gj + ((ky * d) * a.IW + kx * d) * a.SG;
-          float bv[WN];
-#pragma unroll
-          for (int nn = 0; nn < WN; ++nn) bv[nn] = gt[nn * 16];
-#pragma unroll
-          for (int m = 0; m < WM; ++m)
-#pragma unroll
-            for (int nn = 0; nn < WN; ++nn)
-              acc[ky * 3 + kx][m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[nn], acc[ky * 3 + kx][m][nn], 0, 0, 0);
-        }
+        for (int m = 0; m < WM; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv, acc[t][m], 0, 0, 0);
+      }
     }
   }
 
   // ---- reduce the WAVES_K pixel-slices of the workgroup (fixed order) ----
   if (WAVES_K > 1) {
-    constexpr int PER_WAVE = 9 * WM * WN * 4 * 64;
+    constexpr int PER_WAVE = NACC * WM * 4 * 64;
     for (int kk = 1; kk < WAVES_K; ++kk) {
       __syncthreads();
       float* sc = smem + (wave_m * WAVES_N + wave_n) * PER_WAVE;
       if (wave_k == kk) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NACC; ++t)
 #pragma unroll
           for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int nn = 0; nn < WN; ++nn)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) sc[(((t * WM + m) * WN + nn) * 4 + r) * 64 + lane] = acc[t][m][nn][r];
+            for (int r = 0; r < 4; ++r) sc[((t * WM + m) * 4 + r) * 64 + lane] = acc[t][m][r];
       }
       __syncthreads();
       if (wave_k == 0) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NACC; ++t)
 #pragma unroll
           for (int m = 0; m < WM; ++m)
 #pragma unroll
-            for (int nn = 0; nn < WN; ++nn)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[t][m][nn][r] += sc[(((t * WM + m) * WN + nn) * 4 + r) * 64 + lane];
+            for (int r = 0; r < 4; ++r) acc[t][m][r] += sc[((t * WM + m) * 4 + r) * 64 + lane];
       }
     }
   }
   if (wave_k == 0) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NACC; ++t) {
+      int tap, ca;
+      if (FOLD) {
+        const int nn = t * 16 + l15;
+        tap = nn / a.CA; ca = nn - tap * a.CA;
+        if (nn >= 9 * a.CA) continue;
+      } else {
+        tap = t / WN;
+        ca = ca0 + (wave_n * WN + (t % WN)) * 16 + l15;
+      }
 #pragma unroll
       for (int m = 0; m < WM; ++m)
 #pragma unroll
-        for (int nn = 0; nn < WN; ++nn) {
-          const int ca = ca0 + (wave_n * WN + nn) * 16 + l15;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int cb = cb0 + (wave_m * WM + m) * 16 + 4 * l4 + r;
-            if (cb < a.CBP && ca < a.CAP)
-              a.part[(((size_t)blockIdx.x * 9 + t) * a.CBP + cb) * a.CAP + ca] = acc[t][m][nn][r];
-          }
+        for (int r = 0; r < 4; ++r) {
+          const int cb = cb0 + (wave_m * WM + m) * 16 + 4 * l4 + r;
+          if (cb < a.CBP && ca < a.CAP) a.part[(((size_t)blockIdx.x * 9 + tap) * a.CBP + cb) * a.CAP + ca] = acc[t][m][r];
         }
+    }
   }
   // ---- bias partial: sum over the threads that staged the same channel quad (fixed order) ----
   if (a.part_bias && ca_tile == 0) {
-    constexpr int Q = CBT / 4;
     __syncthreads();
     float4* sb = reinterpret_cast<float4*>(smem);
     sb[tid] = bsum;
     __syncthreads();
-    if (tid < Q) {
+    if (tid < QP) {
       float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int e = tid; e < NT; e += Q) { const float4 v = sb[e]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
+      for (int e = tid; e < NT; e += QP) { const float4 v = sb[e]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
       const int cb = cb0 + 4 * tid;
       if (cb < a.CBP) *reinterpret_cast<float4*>(a.part_bias + (size_t)blockIdx.x * a.CBP + cb) = u;
     }
@@ -314,31 +381,52 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // --------------------------------------------------------------------------------------------
-struct WTile { int WM, WN, WAVES_M, WAVES_N, WAVES_K; int cbt() const { return WM * WAVES_M * 16; } int cat() const { return WN * WAVES_N * 16; } };
-static const WTile kWT[] = {
-    {2, 2, 2, 2, 1},  // 0: 64 x 64
-    {2, 2, 2, 1, 2},  // 1: 64 x 32
-    {2, 2, 1, 2, 2},  // 2: 32 x 64
-    {2, 2, 1, 1, 4},  // 3: 32 x 32
-    {2, 1, 1, 1, 4},  // 4: 32 x 16
-    {1, 2, 1, 1, 4},  // 5: 16 x 32
-    {1, 1, 1, 1, 4},  // 6: 16 x 16
+// host side
+// --------------------------------------------------------------------------------------------
+struct WTile {
+  int WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, XP, XG;
+  int cbt() const { return WM * WAVES_M * 16; }
+  int cat() const { return WN * WAVES_N * 16; }
+  int nt() const { return WAVES_M * WAVES_N * WAVES_K * 64; }
 };
+static const WTile kWT[] = {
+    {2, 2, 2, 2, 1, 0, 6, 16},  // 0: 64 x 64
+    {2, 2, 2, 1, 2, 0, 6, 8},   // 1: 64 x 32
+    {2, 2, 1, 2, 2, 0, 8, 12},  // 2: 32 x 64
+    {2, 2, 1, 1, 4, 0, 8, 8},   // 3: 32 x 32
+    {2, 1, 1, 1, 4, 0, 8, 8},   // 4: 32 x 16
+    {1, 2, 1, 1, 4, 0, 8, 8},   // 5: 16 x 32
+    {1, 1, 1, 1, 4, 0, 8, 8},   // 6: 16 x 16
+    {1, 1, 1, 1, 4, 2, 8, 8},   // 7: 16 x (9 taps x <=3 ch folded into 2 blocks)
+    {1, 1, 1, 1, 4, 5, 8, 8},   // 8: 16 x (9 taps x <=8 ch folded into 5 blocks)
+};
+static const int kNumWT = sizeof(kWT) / sizeof(kWT[0]);
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K>
-static int wlaunch_inst(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-  auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K>;
-  static size_t configured = 0;
-  if (lds > configured) {
-    RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
+template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, int XP, int XG>
+static int wlaunch_inst(const WgradArgs& a, bool gtwo, dim3 grid, size_t lds, hipStream_t s) {
+  constexpr int NT = WAVES_M * WAVES_N * WAVES_K * 64;
+  if (gtwo) {
+    auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, XP, XG, true>;
+    static size_t configured = 0;
+    if (lds > configured) {
+      RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = lds;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, a);
+  } else {
+    auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, XP, XG, false>;
+    static size_t configured = 0;
+    if (lds > configured) {
+      RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = lds;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, a);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * WAVES_K * 64), lds, s, a);
   RCV_HIP(hipGetLastError());
   return RCV_OK;
 }
 
-struct WPlan { int tile; int R, Wt, Wt4, tiles_x, tiles_y, IH, IW, SP, SG, nsplit, pl_floats; size_t lds; dim3 grid; int CAP, CBP; };
+struct WPlan { int tile; int R, Wt, Wt4, tiles_x, tiles_y, IH, IW, SP, SG, nsplit, pl_floats, gl_floats; size_t lds; dim3 grid; int CAP, CBP; };
 
 static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   const int N = op->i[RCV_I_N], H = op->i[RCV_I_H], W = op->i[RCV_I_W];
@@ -349,57 +437,67 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   RCV_CHECK_ARG((s == 1 || s == 2) && (d == 1 || d == 2), "wgrad: stride %d dilation %d unsupported", s, d);
   RCV_CHECK_ARG(Hp == (H - 1) / s + 1 && Wp == (W - 1) / s + 1, "wgrad: pointwise plane %dx%d does not match %dx%d / %d", Hp, Wp, H, W, s);
   RCV_CHECK_ARG(CB % 4 == 0, "wgrad: pointwise channels %d must be a multiple of 4", CB);
-  if (op->i[RCV_I_INMODE] == RCV_LOAD_NCHW) RCV_CHECK_ARG(CA <= 4, "wgrad: NCHW gathered operand supports <=4 channels");
+  const bool nchw = op->i[RCV_I_INMODE] == RCV_LOAD_NCHW;
+  if (nchw) RCV_CHECK_ARG(CA <= 4, "wgrad: NCHW gathered operand supports <=4 channels");
   else RCV_CHECK_ARG(CA % 4 == 0, "wgrad: gathered channels %d must be a multiple of 4", CA);
   pl->CAP = round_up(CA, 16); pl->CBP = round_up(CB, 16);
   const int cbt_want = pl->CBP >= 64 ? 64 : (pl->CBP >= 32 ? 32 : 16);
   const int cat_want = pl->CAP >= 64 ? 64 : (pl->CAP >= 32 ? 32 : 16);
   pl->tile = -1;
-  for (int t = 0; t < 7; ++t) if (kWT[t].cbt() == cbt_want && kWT[t].cat() == cat_want) pl->tile = t;
-  if (pl->tile < 0) {  // 64x16 / 16x64 combinations: fall back to the widest tile not exceeding both
-    const int cb2 = cbt_want > 32 ? 32 : cbt_want, ca2 = cat_want > 32 ? 32 : cat_want;
-    for (int t = 0; t < 7; ++t) if (kWT[t].cbt() == cb2 && kWT[t].cat() == ca2) pl->tile = t;
+  const bool fold = CA <= 8 && cbt_want == 16 && !getenv("RCV_NO_FOLD");
+  if (fold) pl->tile = 9 * CA <= 32 ? 7 : 8;
+  else {
+    for (int t = 0; t < 7; ++t) if (kWT[t].cbt() == cbt_want && kWT[t].cat() == cat_want) pl->tile = t;
+    if (pl->tile < 0) {  // 64x16 / 16x64 combinations: the widest tile not exceeding both
+      const int cb2 = cbt_want > 32 ? 32 : cbt_want, ca2 = cat_want > 32 ? 32 : cat_want;
+      for (int t = 0; t < 7; ++t) if (kWT[t].cbt() == cb2 && kWT[t].cat() == ca2) pl->tile = t;
+    }
   }
   RCV_CHECK_ARG(pl->tile >= 0, "wgrad: no tile for %d x %d channels", CB, CA);
   const WTile& wt = kWT[pl->tile];
+  const int QG = fold ? ceil_div(CA, 4) : wt.cat() / 4;
   pl->SP = wt.cbt() % 32 == 0 ? wt.cbt() + 16 : wt.cbt();
-  pl->SG = s == 1 ? (wt.cat() % 32 == 0 ? wt.cat() + 16 : wt.cat()) : wt.cat() + 8;
-  // pixel tile: full rows when the plane is narrow, otherwise row segments; fit a 64 KiB LDS budget
+  if (fold) pl->SG = 4 * QG + 1;
+  else pl->SG = s == 1 ? (wt.cat() % 32 == 0 ? wt.cat() + 16 : wt.cat()) : wt.cat() + 8;
+  // pixel tile: widest row segment, then as many rows as the prefetch registers and the LDS budget allow
   const size_t budget = 80 * 1024 / sizeof(float);   // two workgroups per CU
-  int Wt = Wp, nx = 1;
-  while (true) {
-    Wt = ceil_div(Wp, nx);
-    const int Wt4 = round_up(Wt, 4);
-    const size_t f = (size_t)Wt4 * pl->SP + (size_t)(2 * d + 1) * ((Wt4 - 1) * s + 2 * d + 1) * pl->SG;
-    if (f <= budget || Wt <= 4) break;
-    ++nx;
+  int bestR = 0, bestWt = 0;
+  for (int nx = 1; nx <= Wp && bestR == 0; ++nx) {
+    const int Wt = ceil_div(Wp, nx), Wt4 = round_up(Wt, 4);
+    const int IW = (Wt4 - 1) * s + 2 * d + 1;
+    for (int R = Hp; R >= 1; --R) {
+      const int IH = (R - 1) * s + 2 * d + 1;
+      if (R * Wt4 > 640 || IH * IW >= 65536) continue;
+      if ((size_t)R * Wt4 * pl->SP + (size_t)IH * IW * pl->SG > budget) continue;
+      bestR = R; bestWt = Wt;
+      break;
+    }
   }
-  int R = 1;
-  const int Wt4 = round_up(Wt, 4);
-  const int IW = (Wt4 - 1) * s + 2 * d + 1;
-  while (R < Hp) {
-    const int r2 = R + 1;
-    const size_t f = (size_t)r2 * Wt4 * pl->SP + (size_t)((r2 - 1) * s + 2 * d + 1) * IW * pl->SG;
-    if (f > budget || r2 * Wt4 > 640) break;
-    R = r2;
-  }
-  R = ceil_div(Hp, ceil_div(Hp, R));
-  pl->R = R; pl->Wt = Wt; pl->Wt4 = Wt4; pl->IW = IW; pl->IH = (R - 1) * s + 2 * d + 1;
-  pl->tiles_x = ceil_div(Wp, Wt); pl->tiles_y = ceil_div(Hp, R);
-  RCV_CHECK_ARG(pl->IH * pl->IW < 65536 && R * Wt4 < 65536, "wgrad: tile too large");
+  RCV_CHECK_ARG(bestR > 0, "wgrad: no pixel tile fits (plane %dx%d)", Hp, Wp);
+  const int R = ceil_div(Hp, ceil_div(Hp, bestR));
+  const int Wt4 = round_up(bestWt, 4);
+  pl->R = R; pl->Wt = bestWt; pl->Wt4 = Wt4; pl->IW = (Wt4 - 1) * s + 2 * d + 1; pl->IH = (R - 1) * s + 2 * d + 1;
+  pl->tiles_x = ceil_div(Wp, bestWt); pl->tiles_y = ceil_div(Hp, R);
   pl->pl_floats = round_up(R * Wt4 * pl->SP, 4);
-  size_t floats = (size_t)pl->pl_floats + (size_t)pl->IH * pl->IW * pl->SG;
-  const size_t red = (size_t)wt.WAVES_M * wt.WAVES_N * 9 * wt.WM * wt.WN * 4 * 64;
+  pl->gl_floats = round_up(pl->IH * pl->IW * pl->SG, 4);
+  size_t floats = (size_t)pl->pl_floats + pl->gl_floats;
+  const int nacc = wt.NBF ? wt.NBF : 9 * wt.WN;
+  const size_t red = (size_t)wt.WAVES_M * wt.WAVES_N * nacc * wt.WM * 4 * 64;
   if (wt.WAVES_K > 1 && floats < red) floats = red;
-  const size_t bias_scratch = (size_t)wt.WAVES_M * wt.WAVES_N * wt.WAVES_K * 64 * 4;
+  const size_t bias_scratch = (size_t)wt.nt() * 4;
   if (floats < bias_scratch) floats = bias_scratch;
   pl->lds = floats * sizeof(float);
   RCV_CHECK_ARG(pl->lds <= (size_t)h->max_lds, "wgrad: tile needs %zu B of LDS (limit %d)", pl->lds, h->max_lds);
-  const int ctiles = ceil_div(pl->CBP, wt.cbt()) * ceil_div(pl->CAP, wt.cat());
+  const int ctiles = ceil_div(pl->CBP, wt.cbt()) * (fold ? 1 : ceil_div(pl->CAP, wt.cat()));
   const int ntiles = N * pl->tiles_x * pl->tiles_y;
-  int nsplit = (2 * h->num_cus) / ctiles;
+  int per_cu = (int)((size_t)h->max_lds / pl->lds);
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  if (const char* ev = getenv("RCV_WGRAD_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4) per_cu = o; }
+  int nsplit = (per_cu * h->num_cus) / ctiles;
   if (nsplit < 1) nsplit = 1;
   if (nsplit > ntiles) nsplit = ntiles;
+  nsplit = ceil_div(ntiles, ceil_div(ntiles, nsplit));      // equal tile counts per workgroup
   pl->nsplit = nsplit;
   pl->grid = dim3(nsplit, ctiles, 1);
   return RCV_OK;
@@ -425,7 +523,7 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   if (rc) return rc;
   if (query) {
     const WTile& wt = kWT[pl.tile];
-    snprintf(query->label, sizeof(query->label), "wgrad_mfma<%d,%d,%d,%d,%d>", wt.WM, wt.WN, wt.WAVES_M, wt.WAVES_N, wt.WAVES_K);
+    snprintf(query->label, sizeof(query->label), "wgrad_mfma<%d,%d,%d,%d,%d,f%d>", wt.WM, wt.WN, wt.WAVES_M, wt.WAVES_N, wt.WAVES_K, wt.NBF);
     query->n_part = 0;
     query->n_split = pl.nsplit;
     query->part_bytes = (size_t)pl.nsplit * (9 * (size_t)pl.CBP * pl.CAP + pl.CBP) * sizeof(float);
@@ -441,23 +539,28 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   a.stride = op->i[RCV_I_STRIDE]; a.dil = op->i[RCV_I_DIL];
   a.R = pl.R; a.Wt = pl.Wt; a.Wt4 = pl.Wt4; a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
   a.ntiles = a.N * pl.tiles_x * pl.tiles_y; a.IH = pl.IH; a.IW = pl.IW; a.SP = pl.SP; a.SG = pl.SG;
-  a.nsplit = pl.nsplit; a.pl_floats = pl.pl_floats;
+  a.nsplit = pl.nsplit; a.pl_floats = pl.pl_floats; a.gl_floats = pl.gl_floats;
   a.fdWt4 = make_fastdiv(pl.Wt4); a.fdIW = make_fastdiv(pl.IW);
   RCV_CHECK_ARG(a.g && a.p && a.part, "wgrad: null operand");
   RCV_CHECK_ARG(op->i[RCV_I_NSPLIT] == pl.nsplit, "wgrad: workspace splits %d != %d", op->i[RCV_I_NSPLIT], pl.nsplit);
   RCV_CHECK_ARG(a.p_mode != RCV_LOAD_NCHW, "wgrad: pointwise operand cannot be NCHW");
   RCV_CHECK_ARG(a.g_mode == RCV_LOAD_PLAIN || a.g_mode == RCV_LOAD_NCHW || a.g_c, "wgrad: gathered load mode %d needs constants", a.g_mode);
   RCV_CHECK_ARG(a.p_mode == RCV_LOAD_PLAIN || a.p_c, "wgrad: pointwise load mode %d needs constants", a.p_mode);
-  RCV_CHECK_ARG(!(a.g_mode == RCV_LOAD_GRAD_ENC || a.g_mode == RCV_LOAD_GRAD_DEC) || a.g_aux, "wgrad: gathered gradient load needs aux");
-  RCV_CHECK_ARG(!(a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC) || a.p_aux, "wgrad: pointwise gradient load needs aux");
+  const bool g_two = a.g_mode == RCV_LOAD_GRAD_ENC || a.g_mode == RCV_LOAD_GRAD_DEC;
+  const bool p_two = a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC;
+  RCV_CHECK_ARG(!(g_two && p_two), "wgrad: at most one operand may be a gradient (two-tensor) load");
+  RCV_CHECK_ARG(!g_two || a.g_aux, "wgrad: gathered gradient load needs aux");
+  RCV_CHECK_ARG(!p_two || a.p_aux, "wgrad: pointwise gradient load needs aux");
   a.part_bias = (op->flags & RCV_F_BIAS) ? a.part + (size_t)pl.nsplit * 9 * pl.CBP * pl.CAP : nullptr;
   switch (pl.tile) {
-    case 0: return wlaunch_inst<2, 2, 2, 2, 1>(a, pl.grid, pl.lds, s);
-    case 1: return wlaunch_inst<2, 2, 2, 1, 2>(a, pl.grid, pl.lds, s);
-    case 2: return wlaunch_inst<2, 2, 1, 2, 2>(a, pl.grid, pl.lds, s);
-    case 3: return wlaunch_inst<2, 2, 1, 1, 4>(a, pl.grid, pl.lds, s);
-    case 4: return wlaunch_inst<2, 1, 1, 1, 4>(a, pl.grid, pl.lds, s);
-    case 5: return wlaunch_inst<1, 2, 1, 1, 4>(a, pl.grid, pl.lds, s);
-    default: return wlaunch_inst<1, 1, 1, 1, 4>(a, pl.grid, pl.lds, s);
+    case 0: return wlaunch_inst<2, 2, 2, 2, 1, 0, 6, 16>(a, g_two, pl.grid, pl.lds, s);
+    case 1: return wlaunch_inst<2, 2, 2, 1, 2, 0, 6, 8>(a, g_two, pl.grid, pl.lds, s);
+    case 2: return wlaunch_inst<2, 2, 1, 2, 2, 0, 8, 12>(a, g_two, pl.grid, pl.lds, s);
+    case 3: return wlaunch_inst<2, 2, 1, 1, 4, 0, 8, 8>(a, g_two, pl.grid, pl.lds, s);
+    case 4: return wlaunch_inst<2, 1, 1, 1, 4, 0, 8, 8>(a, g_two, pl.grid, pl.lds, s);
+    case 5: return wlaunch_inst<1, 2, 1, 1, 4, 0, 8, 8>(a, g_two, pl.grid, pl.lds, s);
+    case 6: return wlaunch_inst<1, 1, 1, 1, 4, 0, 8, 8>(a, g_two, pl.grid, pl.lds, s);
+    case 7: return wlaunch_inst<1, 1, 1, 1, 4, 2, 8, 8>(a, g_two, pl.grid, pl.lds, s);
+    default: return wlaunch_inst<1, 1, 1, 1, 4, 5, 8, 8>(a, g_two, pl.grid, pl.lds, s);
   }
 }
