@@ -88,6 +88,7 @@ struct ConvPlan {
   size_t lds;
   int wl_floats, xl_floats;
   int narrow;            // 1: convs_mfma.hip (persistent, filter resident in LDS)
+  int dma;               // 1: conv_dma_kernel (filter chunks by LDS-DMA, double buffered)
   int WM, WN, XMAX;      // narrow kernel template selection
 };
 

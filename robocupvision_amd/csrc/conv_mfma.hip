@@ -103,6 +103,121 @@ __device__ __forceinline__ void stage_input(const ConvArgs& a, float* xl, const 
   }
 }
 
+// Epilogue shared by the conv kernels: bias / ReLU / skip-gradient add, 16-byte NHWC stores, and the per-tile
+// BatchNorm partial sums (forward or backward), reduced in a fixed order through `red` ([WAVES_N][2][COT]).
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const TileInfo& ti, f32x4 (&acc)[WM][WN], float* red, int tid) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int COT = WM * WAVES_M * 16;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int l15 = lane & 15, l4 = lane >> 4;
+    float s1[WM][4], s2[WM][4];
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[m][r] = 0.f; s2[m][r] = 0.f; }
+#pragma unroll
+    for (int m = 0; m < WM; ++m) {
+      const int cov = ti.co0 + (wave_m * WM + m) * 16 + 4 * l4;     // (virtual) output channel of this lane
+      int co = cov, py = ti.py, pxx = ti.px;
+      if (KIND == KIND_TMERGED) { const int ph = cov / a.Cout; co = cov - ph * a.Cout; py = ph >> 1; pxx = ph & 1; }
+      const bool co_ok = cov < a.CoutV;
+      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 e0 = bias, e1 = bias, mu = bias;
+      if (co_ok) {
+        if (a.flags & RCV_F_BIAS) bias = ld4(a.bias + co);
+        if (a.stats == RCV_STATS_BWD_DEC) { e0 = ld4(a.epi_c + co); e1 = ld4(a.epi_c + a.Cout + co); }
+        if (a.stats == RCV_STATS_BWD_DEC || a.stats == RCV_STATS_BWD_ENC) mu = ld4(a.epi_c + 2 * a.Cout + co);
+      }
+#pragma unroll
+      for (int b = 0; b < WN; ++b) {
+        const int p = (wave_n * WN + b) * 16 + l15;
+        const int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
+        int oy = ti.y0 + ty, ox = ti.x0 + tx;
+        bool ok = ty < a.R && co_ok;
+        if (KIND != KIND_GATHER) {
+          ok = ok && oy < a.H && ox < a.W;
+          oy = 2 * oy + py; ox = 2 * ox + pxx;
+        } else {
+          ok = ok && oy < a.Ho && ox < a.Wo;
+        }
+        if (!ok) continue;
+        const size_t off = ((size_t)(ti.n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+        float4 v = make_float4(acc[m][b][0] + bias.x, acc[m][b][1] + bias.y, acc[m][b][2] + bias.z, acc[m][b][3] + bias.w);
+        if (a.flags & RCV_F_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (a.flags & RCV_F_RESID) { const float4 rr = ld4(a.resid + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+        *reinterpret_cast<float4*>(a.out + off) = v;
+        if (a.stats == RCV_STATS_FWD) {
+          s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+          s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
+          s2[m][2] = fmaf(v.z, v.z, s2[m][2]); s2[m][3] = fmaf(v.w, v.w, s2[m][3]);
+        } else if (a.stats == RCV_STATS_BWD_ENC) {
+          const float4 e = ld4(a.epi_aux + off);
+          s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+          s2[m][0] = fmaf(v.x, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(v.y, e.y - mu.y, s2[m][1]);
+          s2[m][2] = fmaf(v.z, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(v.w, e.w - mu.w, s2[m][3]);
+        } else if (a.stats == RCV_STATS_BWD_DEC) {
+          const float4 e = ld4(a.epi_aux + off);
+          const float gx = fmaf(e.x, e0.x, e1.x) > 0.f ? v.x : 0.f;
+          const float gy = fmaf(e.y, e0.y, e1.y) > 0.f ? v.y : 0.f;
+          const float gz = fmaf(e.z, e0.z, e1.z) > 0.f ? v.z : 0.f;
+          const float gw = fmaf(e.w, e0.w, e1.w) > 0.f ? v.w : 0.f;
+          s1[m][0] += gx; s1[m][1] += gy; s1[m][2] += gz; s1[m][3] += gw;
+          s2[m][0] = fmaf(gx, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(gy, e.y - mu.y, s2[m][1]);
+          s2[m][2] = fmaf(gz, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(gw, e.w - mu.w, s2[m][3]);
+        }
+      }
+    }
+    if (a.stats != RCV_STATS_NONE) {
+      // wave: sum over the 16 pixel lanes (xor 1,2,4,8 stays inside a 16-lane group); fixed order
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float u = s1[m][r], v = s2[m][r];
+#pragma unroll
+          for (int sh = 1; sh < 16; sh <<= 1) { u += __shfl_xor(u, sh); v += __shfl_xor(v, sh); }
+          s1[m][r] = u; s2[m][r] = v;
+        }
+      if (l15 == 0) {
+#pragma unroll
+        for (int m = 0; m < WM; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int cl_ = (wave_m * WM + m) * 16 + 4 * l4 + r;
+            red[(wave_n * 2 + 0) * COT + cl_] = s1[m][r];
+            red[(wave_n * 2 + 1) * COT + cl_] = s2[m][r];
+          }
+      }
+      __syncthreads();
+      const size_t row = (size_t)(KIND == KIND_TPHASE ? (ti.py * 2 + ti.px) * a.n_pix_tiles : 0) + ti.pt;
+      if (KIND == KIND_TMERGED) {
+        // real channel = virtual channel mod Cout: sum the (up to) four parity groups in fixed order
+        for (int e = tid; e < 2 * a.Cout; e += NT) {
+          const int which = e / a.Cout, co = e - which * a.Cout;
+          float u = 0.f;
+          for (int cv = co; cv < a.CoutV; cv += a.Cout) {
+#pragma unroll
+            for (int wn = 0; wn < WAVES_N; ++wn) u += red[(wn * 2 + which) * COT + cv];
+          }
+          a.part[(row * 2 + which) * a.Cout + co] = u;
+        }
+      } else {
+        for (int e = tid; e < 2 * COT; e += NT) {
+          const int which = e / COT, cl_ = e % COT;
+          const int co = ti.co0 + cl_;
+          if (co < a.Cout) {
+            float u = 0.f;
+#pragma unroll
+            for (int wn = 0; wn < WAVES_N; ++wn) u += red[(wn * 2 + which) * COT + cl_];
+            a.part[(row * 2 + which) * a.Cout + co] = u;
+          }
+        }
+      }
+  }
+}
+
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, int KIND>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -224,116 +339,215 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const 
     }
   }
 
-  // ---------------------------------- epilogue ----------------------------------
-    float s1[WM][4], s2[WM][4];
+  conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND>(a, ti, acc, red, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Wide layers (COT >= 64): the filter chunk is ~90 % of the staged bytes and needs no transform, so it goes
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4: no registers, asynchronous) into a DOUBLE buffer while
+// the previous chunk is being contracted; the small input chunk rides along in a few registers.  One barrier
+// per chunk, and the L2 latency of the filter stream is hidden behind ~90 MFMAs per wave.
+//   LDS: wl[2][taps*4][COT] (lane-linear, as the DMA writes it), xl[2][IH*IW][5], constants, reduction scratch.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* rcv_lds_ptr;
+typedef const __attribute__((address_space(1))) void* rcv_glb_ptr;
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND, bool TWO>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const ConvArgs a) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int COT = WM * WAVES_M * 16;
+  constexpr int CK = 4, S = CK + 1;
+  constexpr int WS = COT;                       // unpadded rows: the DMA image is lane-linear
+  constexpr int C4 = COT / 4;
+  constexpr int XMAX = 4, AMAX = TWO ? XMAX : 1;
+  constexpr int NTAPS_MAX = KIND == KIND_GATHER ? 9 : 4;
+  constexpr int WBUF = NTAPS_MAX * CK * WS;     // floats per filter buffer
+  constexpr int WU = (NTAPS_MAX * CK * C4 + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* wl = smem;                             // [2][WBUF]
+  float* xl = smem + 2 * WBUF;                  // [2][xl_floats]
+  float* cl = xl + 2 * a.xl_floats;             // [5][Cin]
+  float* red = cl + 5 * a.CinP + 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int npix = a.IH * a.IW;
+
+  if (a.in_c && a.in_mode != RCV_LOAD_PLAIN && a.in_mode != RCV_LOAD_NCHW)
+    for (int e = tid; e < 5 * a.Cin; e += NT) cl[e] = a.in_c[e];
+
+  const TileInfo ti = decode_tile<KIND>(a, blockIdx.x, COT);
+  int nxt = 3, ntaps = 9;
+  if (KIND == KIND_TPHASE) { nxt = 1 + ti.px; ntaps = (1 + ti.py) * nxt; }
+  if (KIND == KIND_TMERGED) { nxt = 2; ntaps = 4; }
+  const int IS = KIND == KIND_GATHER ? a.stride : 1;
+  const int wtotal = ntaps * CK * C4;           // 16-byte pieces of one filter chunk (a multiple of 64 for COT >= 64)
+
+  auto dma_w = [&](int buf, int c0) {
 #pragma unroll
-    for (int m = 0; m < WM; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[m][r] = 0.f; s2[m][r] = 0.f; }
-#pragma unroll
-    for (int m = 0; m < WM; ++m) {
-      const int cov = ti.co0 + (wave_m * WM + m) * 16 + 4 * l4;     // (virtual) output channel of this lane
-      int co = cov, py = ti.py, pxx = ti.px;
-      if (KIND == KIND_TMERGED) { const int ph = cov / a.Cout; co = cov - ph * a.Cout; py = ph >> 1; pxx = ph & 1; }
-      const bool co_ok = cov < a.CoutV;
-      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 e0 = bias, e1 = bias, mu = bias;
-      if (co_ok) {
-        if (a.flags & RCV_F_BIAS) bias = ld4(a.bias + co);
-        if (a.stats == RCV_STATS_BWD_DEC) { e0 = ld4(a.epi_c + co); e1 = ld4(a.epi_c + a.Cout + co); }
-        if (a.stats == RCV_STATS_BWD_DEC || a.stats == RCV_STATS_BWD_ENC) mu = ld4(a.epi_c + 2 * a.Cout + co);
-      }
-#pragma unroll
-      for (int b = 0; b < WN; ++b) {
-        const int p = (wave_n * WN + b) * 16 + l15;
-        const int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
-        int oy = ti.y0 + ty, ox = ti.x0 + tx;
-        bool ok = ty < a.R && co_ok;
-        if (KIND != KIND_GATHER) {
-          ok = ok && oy < a.H && ox < a.W;
-          oy = 2 * oy + py; ox = 2 * ox + pxx;
-        } else {
-          ok = ok && oy < a.Ho && ox < a.Wo;
+    for (int u = 0; u < WU; ++u) {
+      const int e0 = (u * (NT / 64) + wave) * 64;           // first piece of this wave-instruction (wave uniform)
+      if (e0 < wtotal) {
+        const int e = e0 + lane;
+        const int row = e / C4, c4 = e % C4;
+        const int j = row / CK, ck = row % CK;
+        int t9 = j;
+        if (KIND == KIND_TPHASE) {
+          const int jy = j / nxt, jx = j - jy * nxt;
+          const int ky = ti.py ? (jy ? 2 : 0) : 1;
+          const int kx = ti.px ? (jx ? 2 : 0) : 1;
+          t9 = ky * 3 + kx;
         }
-        if (!ok) continue;
-        const size_t off = ((size_t)(ti.n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
-        float4 v = make_float4(acc[m][b][0] + bias.x, acc[m][b][1] + bias.y, acc[m][b][2] + bias.z, acc[m][b][3] + bias.w);
-        if (a.flags & RCV_F_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (a.flags & RCV_F_RESID) { const float4 rr = ld4(a.resid + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-        *reinterpret_cast<float4*>(a.out + off) = v;
-        if (a.stats == RCV_STATS_FWD) {
-          s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
-          s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
-          s2[m][2] = fmaf(v.z, v.z, s2[m][2]); s2[m][3] = fmaf(v.w, v.w, s2[m][3]);
-        } else if (a.stats == RCV_STATS_BWD_ENC) {
-          const float4 e = ld4(a.epi_aux + off);
-          s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
-          s2[m][0] = fmaf(v.x, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(v.y, e.y - mu.y, s2[m][1]);
-          s2[m][2] = fmaf(v.z, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(v.w, e.w - mu.w, s2[m][3]);
-        } else if (a.stats == RCV_STATS_BWD_DEC) {
-          const float4 e = ld4(a.epi_aux + off);
-          const float gx = fmaf(e.x, e0.x, e1.x) > 0.f ? v.x : 0.f;
-          const float gy = fmaf(e.y, e0.y, e1.y) > 0.f ? v.y : 0.f;
-          const float gz = fmaf(e.z, e0.z, e1.z) > 0.f ? v.z : 0.f;
-          const float gw = fmaf(e.w, e0.w, e1.w) > 0.f ? v.w : 0.f;
-          s1[m][0] += gx; s1[m][1] += gy; s1[m][2] += gz; s1[m][3] += gw;
-          s2[m][0] = fmaf(gx, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(gy, e.y - mu.y, s2[m][1]);
-          s2[m][2] = fmaf(gz, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(gw, e.w - mu.w, s2[m][3]);
+        const float* src = a.w + ((size_t)(t9 * a.CinP + c0 + ck) * a.CoutP + ti.co0 + 4 * c4);
+        float* dst = wl + buf * WBUF + e0 * 4;              // + lane*16 B is added by the hardware
+        __builtin_amdgcn_global_load_lds((rcv_glb_ptr)src, (rcv_lds_ptr)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  float4 px[XMAX], pa[AMAX];
+  uint32_t okmask = 0;
+  auto load_x = [&](int c0) {
+    okmask = 0;
+#pragma unroll
+    for (int u = 0; u < XMAX; ++u) {
+      const int pix = tid + u * NT;
+      px[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (TWO) pa[TWO ? u : 0] = px[u];
+      if (pix < npix) {
+        const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
+        const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
+        if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+          okmask |= 1u << u;
+          const size_t off = ((size_t)(ti.n * a.H + gy) * a.W + gx) * a.Cin + c0;
+          px[u] = ld4(a.in + off);
+          if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
         }
       }
     }
-    if (a.stats != RCV_STATS_NONE) {
-      // wave: sum over the 16 pixel lanes (xor 1,2,4,8 stays inside a 16-lane group); fixed order
+  };
+  auto write_x = [&](int buf, int c0) {
+    float* xb = xl + buf * a.xl_floats;
+    float4 k[5];
+    if (a.in_mode != RCV_LOAD_PLAIN) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) k[j] = *reinterpret_cast<const float4*>(cl + j * a.Cin + c0);
+    }
+#pragma unroll
+    for (int u = 0; u < XMAX; ++u) {
+      const int pix = tid + u * NT;
+      if (pix < npix) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((okmask >> u) & 1u) {
+          switch (a.in_mode) {
+            case RCV_LOAD_PLAIN: v = px[u]; break;
+            case RCV_LOAD_AFFINE: v = xform4<RCV_LOAD_AFFINE>(px[u], px[u], k); break;
+            case RCV_LOAD_AFFINE_RELU: v = xform4<RCV_LOAD_AFFINE_RELU>(px[u], px[u], k); break;
+            case RCV_LOAD_GRAD_ENC: v = xform4<RCV_LOAD_GRAD_ENC>(px[u], pa[TWO ? u : 0], k); break;
+            default: v = xform4<RCV_LOAD_GRAD_DEC>(px[u], pa[TWO ? u : 0], k); break;
+          }
+        }
+        float* d = xb + pix * S;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
+  };
+
+  int pixoff[WN];
+#pragma unroll
+  for (int b = 0; b < WN; ++b) {
+    const int p = (wave_n * WN + b) * 16 + l15;
+    int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
+    if (ty >= a.R) { ty = 0; tx = 0; }
+    pixoff[b] = ((ty * IS) * a.IW + tx * IS) * S + l4;
+  }
+  const int aoff = l4 * WS + (wave_m * WM) * 16 + l15;
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int b = 0; b < WN; ++b) acc[m][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  dma_w(0, 0);
+  load_x(0);
+  const int nchunks = a.CinP / CK;
+  for (int i = 0; i < nchunks; ++i) {
+    const int buf = i & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces and input loads have landed
+    write_x(buf, i * CK);
+    __syncthreads();          // everyone's pieces landed and tile written; everyone finished contracting chunk i-1
+    if (i + 1 < nchunks) {
+      dma_w(buf ^ 1, (i + 1) * CK);                       // in flight during the contraction below
+      load_x((i + 1) * CK);
+    }
+    const float* wb = wl + buf * WBUF;
+    const float* xb = xl + buf * a.xl_floats;
+    for (int j = 0; j < ntaps; ++j) {
+      int dy, dx;
+      const int jy = j / nxt, jx = j - jy * nxt;
+      if (KIND == KIND_TPHASE) {
+        dy = ti.py ? (jy ? 0 : 1) : 0;
+        dx = ti.px ? (jx ? 0 : 1) : 0;
+      } else if (KIND == KIND_TMERGED) {
+        dy = jy; dx = jx;
+      } else {
+        dy = jy * a.dil; dx = jx * a.dil;
+      }
+      const float* wj = wb + j * CK * WS + aoff;
+      const float* xj = xb + (dy * a.IW + dx) * S;
+      float av[WM], bv[WN];
+#pragma unroll
+      for (int m = 0; m < WM; ++m) av[m] = wj[m * 16];
+#pragma unroll
+      for (int b = 0; b < WN; ++b) bv[b] = xj[pixoff[b]];
 #pragma unroll
       for (int m = 0; m < WM; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float u = s1[m][r], v = s2[m][r];
-#pragma unroll
-          for (int sh = 1; sh < 16; sh <<= 1) { u += __shfl_xor(u, sh); v += __shfl_xor(v, sh); }
-          s1[m][r] = u; s2[m][r] = v;
-        }
-      if (l15 == 0) {
-#pragma unroll
-        for (int m = 0; m < WM; ++m)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int cl_ = (wave_m * WM + m) * 16 + 4 * l4 + r;
-            red[(wave_n * 2 + 0) * COT + cl_] = s1[m][r];
-            red[(wave_n * 2 + 1) * COT + cl_] = s2[m][r];
-          }
-      }
-      __syncthreads();
-      const size_t row = (size_t)(KIND == KIND_TPHASE ? (ti.py * 2 + ti.px) * a.n_pix_tiles : 0) + ti.pt;
-      if (KIND == KIND_TMERGED) {
-        // real channel = virtual channel mod Cout: sum the (up to) four parity groups in fixed order
-        for (int e = tid; e < 2 * a.Cout; e += NT) {
-          const int which = e / a.Cout, co = e - which * a.Cout;
-          float u = 0.f;
-          for (int cv = co; cv < a.CoutV; cv += a.Cout) {
-#pragma unroll
-            for (int wn = 0; wn < WAVES_N; ++wn) u += red[(wn * 2 + which) * COT + cv];
-          }
-          a.part[(row * 2 + which) * a.Cout + co] = u;
-        }
-      } else {
-        for (int e = tid; e < 2 * COT; e += NT) {
-          const int which = e / COT, cl_ = e % COT;
-          const int co = ti.co0 + cl_;
-          if (co < a.Cout) {
-            float u = 0.f;
-#pragma unroll
-            for (int wn = 0; wn < WAVES_N; ++wn) u += red[(wn * 2 + which) * COT + cl_];
-            a.part[(row * 2 + which) * a.Cout + co] = u;
-          }
-        }
-      }
+        for (int b = 0; b < WN; ++b)
+          acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[m][b], 0, 0, 0);
+    }
   }
+  conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND>(a, ti, acc, red, tid);
 }
 
 // --------------------------------------------------------------------------------------------
 // Host side: tiling choice and launch
 // --------------------------------------------------------------------------------------------
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND>
+static int launch_dma(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  const bool two = a.in_mode == RCV_LOAD_GRAD_ENC || a.in_mode == RCV_LOAD_GRAD_DEC;
+  if (two) {
+    auto kern = conv_dma_kernel<WM, WN, WAVES_M, WAVES_N, KIND, true>;
+    static size_t configured = 0;
+    if (lds > configured) {
+      RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = lds;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, a);
+  } else {
+    auto kern = conv_dma_kernel<WM, WN, WAVES_M, WAVES_N, KIND, false>;
+    static size_t configured = 0;
+    if (lds > configured) {
+      RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured = lds;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, a);
+  }
+  RCV_HIP(hipGetLastError());
+  return RCV_OK;
+}
+
+template <int KIND>
+static int launch_dma_tile(int tile, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  switch (tile) {
+    case 0: return launch_dma<2, 5, 4, 1, KIND>(a, grid, lds, s);
+    case 1: return launch_dma<2, 5, 2, 2, KIND>(a, grid, lds, s);
+    default: return launch_dma<1, 5, 4, 1, KIND>(a, grid, lds, s);
+  }
+}
+
 struct TileCfg {
   int WM, WN, WAVES_M, WAVES_N, XMAX;
   int cot() const { return WM * WAVES_M * 16; }
@@ -422,6 +636,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   }
   const int CinP = round_up(Cin, 4);
   pl->narrow = 0;
+  pl->dma = 0;
   if (convs_supported(h, op, pl->kind, CinP, pl->kind == KIND_TMERGED ? 4 * Cout : Cout)) return convs_make_plan(h, op, pl->kind, pl);
   pl->CK = (CinP % 8 == 0) ? 8 : 4;
   const int Q = pl->CK / 4;
@@ -429,6 +644,10 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   pl->CoutP = round_up(pl->CoutV, 16);
   const int TH = transposed ? H : Ho, TW = transposed ? W : Wo;
   // candidates by (virtual) output-channel count; minimise padded work, prefer the larger tile on ties
+  // LDS-DMA filter streaming pays where the filter dominates the staged bytes (wide layers); with few input
+  // channels its 4-channel chunks fragment the HBM-bound input reads instead
+  const bool use_dma = mode != RCV_LOAD_NCHW && Cin >= 64 && !getenv("RCV_NO_DMA");
+  (void)Q;
   long best = -1;
   pl->tile = -1;
   for (int t = 0; t < kNumTiles; ++t) {
@@ -437,9 +656,10 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
     if (pl->kind == KIND_TMERGED && cot < pl->CoutP) continue;   // merged layout: all parities in one workgroup
     if (pl->CoutP >= 128 && cot < 64) continue;
     if (pl->CoutP >= 64 && cot < 32) continue;
-    const int cap = kTiles[t].nt() * kTiles[t].XMAX / Q;
+    const bool dma_tile = use_dma && (t == 0 || t == 1 || t == 4);
+    const int cap = dma_tile ? kTiles[t].nt() * 4 : 65535;      // DMA variant: input chunk rides in 4 registers per thread
     int R, Wt, tx, ty;
-    if (!plan_tile(pl->kind, TH, TW, kTiles[t].pix(), s, d, cap < 65535 ? cap : 65535, &R, &Wt, &tx, &ty)) continue;
+    if (!plan_tile(pl->kind, TH, TW, kTiles[t].pix(), s, d, cap, &R, &Wt, &tx, &ty)) continue;
     const long work = (long)tx * ty * kTiles[t].pix() * round_up(pl->CoutP, cot);
     if (best < 0 || work < best || (work == best && kTiles[t].pix() * cot > kTiles[pl->tile].pix() * kTiles[pl->tile].cot())) {
       best = work; pl->tile = t; pl->R = R; pl->Wt = Wt; pl->tiles_x = tx; pl->tiles_y = ty;
@@ -456,9 +676,18 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   const TileCfg& tc = kTiles[pl->tile];
   tile_halo(pl->kind, pl->R, pl->Wt, s, d, &pl->IH, &pl->IW);
   const int ntaps = pl->kind == KIND_GATHER ? 9 : 4;
-  pl->wl_floats = round_up(ntaps * pl->CK * (tc.cot() + 16), 4);
-  pl->xl_floats = round_up(pl->IH * pl->IW * (pl->CK + 1), 4);
-  const size_t floats = (size_t)pl->wl_floats + pl->xl_floats + 5 * CinP + 16 + (size_t)tc.WAVES_N * 2 * tc.cot();
+  pl->dma = use_dma && (pl->tile == 0 || pl->tile == 1 || pl->tile == 4) && pl->IH * pl->IW <= tc.nt() * 4;
+  size_t floats;
+  if (pl->dma) {
+    pl->CK = 4;
+    pl->wl_floats = ntaps * 4 * tc.cot();
+    pl->xl_floats = round_up(pl->IH * pl->IW * 5, 4);
+    floats = 2 * (size_t)pl->wl_floats + 2 * (size_t)pl->xl_floats + 5 * CinP + 16 + (size_t)tc.WAVES_N * 2 * tc.cot();
+  } else {
+    pl->wl_floats = round_up(ntaps * pl->CK * (tc.cot() + 16), 4);
+    pl->xl_floats = round_up(pl->IH * pl->IW * (pl->CK + 1), 4);
+    floats = (size_t)pl->wl_floats + pl->xl_floats + 5 * CinP + 16 + (size_t)tc.WAVES_N * 2 * tc.cot();
+  }
   pl->lds = floats * sizeof(float);
   RCV_CHECK_ARG(pl->lds <= (size_t)h->max_lds, "conv: tile needs %zu B of LDS (limit %d)", pl->lds, h->max_lds);
   pl->n_co_tiles = ceil_div(pl->CoutP, tc.cot());
@@ -482,7 +711,8 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
       snprintf(query->label, sizeof(query->label), "%ss_mfma<%d,%d,%d>", kn[pl.kind], pl.WM, pl.WN, pl.CK);
     } else {
       const TileCfg& tc = kTiles[pl.tile];
-      snprintf(query->label, sizeof(query->label), "%s_mfma<%d,%d,%d,%d,%d>", kn[pl.kind], tc.WM, tc.WN, tc.WAVES_M, tc.WAVES_N, pl.CK);
+      snprintf(query->label, sizeof(query->label), "%s_%s<%d,%d,%d,%d,%d>", kn[pl.kind], pl.dma ? "dma" : "mfma", tc.WM, tc.WN, tc.WAVES_M,
+               tc.WAVES_N, pl.CK);
     }
     query->n_part = op->i[RCV_I_STATS] != RCV_STATS_NONE ? n_part : 0;
     query->n_split = 0;
@@ -521,6 +751,11 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   RCV_CHECK_ARG(!(a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC) || a.epi_c, "conv: backward statistics need epi_c (scale, shift, mean)");
   if (pl.narrow) return convs_launch(pl, a, a.in_mode == RCV_LOAD_GRAD_ENC || a.in_mode == RCV_LOAD_GRAD_DEC, s);
   const dim3 grid(pl.grid);
+  if (pl.dma) {
+    if (pl.kind == KIND_TPHASE) return launch_dma_tile<KIND_TPHASE>(pl.tile, a, grid, pl.lds, s);
+    if (pl.kind == KIND_TMERGED) return launch_dma_tile<KIND_TMERGED>(pl.tile, a, grid, pl.lds, s);
+    return launch_dma_tile<KIND_GATHER>(pl.tile, a, grid, pl.lds, s);
+  }
   if (pl.kind == KIND_TPHASE)
     return pl.CK == 8 ? launch_tile<8, KIND_TPHASE>(pl.tile, a, grid, pl.lds, s) : launch_tile<4, KIND_TPHASE>(pl.tile, a, grid, pl.lds, s);
   if (pl.kind == KIND_TMERGED)
