@@ -98,8 +98,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("RCV_FORCE_COLLECTIVES"):
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -113,7 +117,7 @@ def main():
     model = M.ROBO_UNet(**ctor).to(dev)
     x, t = synthetic(B, H, W, seed=1 + rank)
     x, t = x.to(dev), t.to(dev)
-    trainer = Trainer(model, class_weights=[1, 10, 30, 10, 2], lr=1e-3, decay=1e-6, distributed=world > 1)
+    trainer = Trainer(model, class_weights=[1, 10, 30, 10, 2], lr=1e-3, decay=1e-6, distributed=dist is not None)
 
     for _ in range(args.warmup):
         trainer.step(x, t)

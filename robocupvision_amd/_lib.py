@@ -130,6 +130,11 @@ class OpList:
         if self.n:
             check(load().rcv_run(h, self.arr, self.n, C.c_void_p(stream_ptr)), "rcv_run")
 
+    def run_slice(self, h, stream_ptr: int, start: int, end: int):
+        if end > start:
+            first = C.cast(C.byref(self.arr, start * C.sizeof(RcvOp)), C.POINTER(RcvOp))
+            check(load().rcv_run(h, first, end - start, C.c_void_p(stream_ptr)), "rcv_run")
+
     def run_timed(self, h, stream_ptr: int):
         """Profiling aid: per-op milliseconds (HIP events around every op; synchronises)."""
         ms = (C.c_float * max(self.n, 1))()

@@ -37,6 +37,19 @@ def _round_up(a: int, b: int) -> int:
     return (a + b - 1) // b * b
 
 
+def select_buckets(marks, numel: int, n_buckets: int):
+    """Pick <= n_buckets (ops_end, lo_offset) marks so that each bucket carries about numel/n_buckets gradients."""
+    if not marks:
+        return []
+    out, target, hi = [], max(numel // max(n_buckets, 1), 1), numel
+    for k, (end, lo) in enumerate(marks):
+        last = k == len(marks) - 1
+        if (hi - lo >= target and len(out) < n_buckets - 1) or last:
+            out.append((end, lo))
+            hi = lo
+    return out
+
+
 class Value:
     """A tensor of the graph together with how consumers must read it."""
 
@@ -115,6 +128,7 @@ class Plan:
         self.dlogits_slots: List[tuple] = []
         self.logits: Optional[torch.Tensor] = None
         self.input_grads: List[Optional[torch.Tensor]] = []
+        self.bwd_marks: List = []            # [(ops executed, lowest final flat-gradient offset)]
         self.bytes = 0
 
 
@@ -127,6 +141,9 @@ class Engine:
         self.plans: Dict[tuple, Plan] = {}
         self.device: Optional[torch.device] = None
         self.handle = None
+        # data parallel: called as cb(lo, hi) during backward whenever flat.grad[lo:hi] is final (reverse layer order)
+        self.grad_ready_cb = None
+        self.grad_buckets = 3
 
     # ------------------------------------------------------------------ device / parameter state
     def _ensure_device(self, dev: torch.device):
@@ -318,6 +335,21 @@ class Engine:
                 fwd.append(op)
                 node.out = Value("plain", logits, Cout, src.H, src.W, None, node)
                 plan.logits = logits
+            elif node.op == "add_slice":
+                # out = value(src); out[..., 0:Ca] += value(add)      (LabelProp tail, model.py:565)
+                src, add = ref(d["src"]), ref(d["add"])
+                if (add.H, add.W) != (src.H, src.W) or add.C > src.C:
+                    raise L.RcvError("add_slice: operand shapes do not match")
+                out = self._alloc(plan, N, src.H, src.W, src.C)
+                op = L.make_op(L.OP_MATERIALIZE, 0, n=N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
+                               p_in_c=_ptr(src.consts), p_out=out.data_ptr())
+                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
+                fwd.append(op)
+                op2 = L.make_op(L.OP_ADD_SLICE, 0, n=N, h=src.H, w=src.W, cin=add.C, cout=src.C, inmode=add.load_mode,
+                                p_in_c=_ptr(add.consts), p_out=out.data_ptr())
+                op2.p[L.RCV_P_IN] = bind_in(fwd, add, L.RCV_P_IN) or None
+                fwd.append(op2)
+                node.out = Value("plain", out, src.C, src.H, src.W, None, node)
             elif node.op == "mat":
                 src = ref(d["src"])
                 out = self._alloc(plan, N, src.H, src.W, src.C)
@@ -335,6 +367,8 @@ class Engine:
         if training:
             # which values need a gradient: everything produced by a node, plus flagged inputs
             for node in nodes:
+                if node.op == "add_slice":
+                    raise L.RcvError("this graph is inference only (add_slice has no backward); call .eval()")
                 if node.op not in ("cls", "mat"):
                     node.out.needs_grad = True
 
@@ -371,8 +405,18 @@ class Engine:
                                      p_x0=bn.weight.data_ptr(), p_x1=fl.grad_ptr(bn.weight), p_x2=fl.grad_ptr(bn.bias),
                                      p_x4=node.t["mean"].data_ptr(), p_x5=node.t["istd"].data_ptr()))
 
+            def node_params(nd):
+                ps = [nd.d.get("weight"), nd.d.get("bias")]
+                bn_ = nd.d.get("bn")
+                if bn_ is not None:
+                    ps += [bn_.weight, bn_.bias]
+                return [q for q in ps if q is not None]
+
             for node in reversed(nodes):
                 d = node.d
+                if bwd and node_params(node):
+                    pass
+                plan.bwd_marks.append([len(bwd), node])      # patched to (op count after this node, min flat offset) below
                 if node.op == "cls":
                     src = ref(d["src"])
                     w, b = d["weight"], d.get("bias")
@@ -477,6 +521,20 @@ class Engine:
                         grad_target(src, dop, src.H, src.W)
                         bwd.append(dop)
 
+        # gradient-ready marks: after bwd ops [0:end) every parameter at flat offset >= lo is final (parameters are laid
+        # out in forward order and backward visits the nodes in reverse, so the finished region is a growing suffix)
+        marks, lo = [], fl.numel
+        for k, (start, node) in enumerate(plan.bwd_marks):
+            end = plan.bwd_marks[k + 1][0] if k + 1 < len(plan.bwd_marks) else len(bwd)
+            offs = [fl.offsets[fl.index(q)] for q in node_params(node)] if training else []
+            if offs:
+                lo = min(lo, min(offs))
+            if end > 0 and (not marks or marks[-1][0] != end):
+                marks.append((end, lo))
+            elif marks:
+                marks[-1] = (end, min(marks[-1][1], lo))
+        plan.bwd_marks = marks if training else []
+
         # ---- the pack launch goes first in the forward list ----
         table = (L.RcvPackJob * len(jobs))(*jobs)
         nbytes = C.sizeof(table)
@@ -569,5 +627,20 @@ class Engine:
             dlogits = dlogits.to(torch.float32).contiguous()
         for (idx, slot) in plan.dlogits_slots:
             plan.bwd.arr[idx].p[slot] = dlogits.data_ptr()
-        plan.bwd.run(self.handle, torch.cuda.current_stream(self.device).cuda_stream)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if self.grad_ready_cb is None or not plan.bwd_marks:
+            plan.bwd.run(self.handle, stream)
+            return plan
+        # bucketed: run the op list in slices and hand finished gradient ranges to the caller (all-reduce on a side stream)
+        done, hi = 0, self.flat.numel
+        for (end, lo) in select_buckets(plan.bwd_marks, self.flat.numel, self.grad_buckets):
+            plan.bwd.run_slice(self.handle, stream, done, end)
+            done = end
+            if lo < hi:
+                self.grad_ready_cb(lo, hi)
+                hi = lo
+        if done < plan.bwd.n:
+            plan.bwd.run_slice(self.handle, stream, done, plan.bwd.n)
+        if hi > 0:
+            self.grad_ready_cb(0, hi)
         return plan

@@ -407,8 +407,39 @@ class LabelProp(nn.Module):
         self.upConv3 = upSampleTransposeConv(numPlanes // 2, numPlanes // 2)
         self.classifier = nn.Conv2d(numPlanes // 2, numClass, 1, padding=0)
 
+    # graph of model.py:556-567
+    def _graph(self):
+        nodes = []
+
+        def add(node):
+            nodes.append(node)
+            return ("node", len(nodes) - 1)
+
+        top = add(self.pre._node(("in", 0)))
+        middle = add(self.down1._node(top))
+        bottom = add(self.down2._node(middle))
+        x = add(self.down3._node(bottom))
+        x = add(self.conv1._node(x))
+        x = add(self.conv2._node(x))
+        x = add(self.conv3._node(x))
+        x = add(self.upConv1._node(x, bottom))          # bottom + upConv1(x)
+        x = add(self.upConv2._node(x, middle))          # middle + upConv2(x)
+        x = add(self.upConv3._node(x, None))
+        x = add({"op": "add_slice", "src": x, "add": top})      # x[:, 0:8] += top
+        add({"op": "cls", "src": x, "weight": self.classifier.weight, "bias": self.classifier.bias})
+        return {"inputs": [{"layout": "nhwc", "requires_grad": False}], "nodes": nodes}
+
     def forward(self, x):
-        raise L.RcvError("LabelProp inference is a later row of the scope table (not built yet)")
+        """Inference only (BASELINE config 5): x float32 [B,8,H,W] -> logits [B,numClass,H,W]."""
+        if self.training:
+            raise L.RcvError("LabelProp is built for inference only; call .eval()")
+        if x.dim() != 4 or x.shape[1] != 8 or x.shape[2] % 8 or x.shape[3] % 8:
+            raise ValueError("LabelProp expects float32 [B,8,H,W] with H,W multiples of 8, got %s" % (tuple(x.shape),))
+        eng = self.__dict__.get("_engine")
+        if eng is None:
+            eng = Engine(self._graph(), list(self.parameters()), _bn_modules(self))
+            self.__dict__["_engine"] = eng
+        return _run_engine(eng, False, [x.to(torch.float32).permute(0, 2, 3, 1).contiguous()])
 
 
 # ------------------------------------------------------------------------------------------

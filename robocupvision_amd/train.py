@@ -15,6 +15,7 @@ identical optimizer step, running BN buffers stay per rank (rank 0 is authoritat
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -39,6 +40,7 @@ class Trainer:
         self.distributed = distributed
         self.world = 1
         self.comm_stream = None
+        self.force_collectives = bool(int(os.environ.get("RCV_FORCE_COLLECTIVES", "0")))   # exercise the path at world size 1
         if distributed:
             import torch.distributed as dist
             if not dist.is_initialized():
@@ -50,18 +52,18 @@ class Trainer:
             for p in model.parameters():
                 dist.broadcast(p.data, 0)
 
-    def _allreduce_grads(self):
+    def _grad_ready(self, lo: int, hi: int):
+        """flat.grad[lo:hi] is final (called from inside backward, reverse layer order): sum it over the ranks on the
+        side stream while the remaining backward kernels keep the compute stream busy."""
         import torch.distributed as dist
         fl = self.model._get_engine().flat
+        bucket = fl.grad[lo:hi]
         if self.comm_stream is None:
-            dist.all_reduce(fl.grad)
+            dist.all_reduce(bucket)
             return
-        # exchange on a side stream so the L1 reduction / metric bookkeeping of this step (and, in the
-        # bucketed variant, the rest of backward) runs beside it; the optimizer waits on the event
-        cur = torch.cuda.current_stream(self.device)
-        self.comm_stream.wait_stream(cur)
+        self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.comm_stream):
-            dist.all_reduce(fl.grad)
+            dist.all_reduce(bucket)
         self._pending = self.comm_stream
 
     def step(self, imgs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
@@ -71,10 +73,10 @@ class Trainer:
         opt.zero_grad(set_to_none=True)
         pred = model(imgs)
         ce = crit(pred, targets)
-        ce.backward()
         self._pending = None
-        if self.distributed and self.world > 1:
-            self._allreduce_grads()
+        eng = model._get_engine()
+        eng.grad_ready_cb = self._grad_ready if (self.distributed and (self.world > 1 or self.force_collectives)) else None
+        ce.backward()
         with torch.no_grad():
             reg = opt.l1_term()
             self.metrics += torch.stack([ce.detach().double() + reg.double(), reg.double(),

@@ -209,3 +209,26 @@ def test_trainer_fused_step_vs_golden(net_kats, net_meta, tag):
     tr.step(x, t)
     tr.step(x, t)
     assert tr.pop_metrics()["loss"] < m["loss"]
+
+
+def test_labelprop_inference_vs_golden():
+    """BASELINE config 5: LabelProp frame-pair inference (model.py:538-567) against the reference's output for
+    seeded weights and an 8-channel input built with the labelPropTrain.py:178-182 recipe."""
+    import os
+    from conftest import GOLDEN
+    kat = np.load(os.path.join(GOLDEN, "labelprop.npz"))
+    torch.manual_seed(12345678)
+    net = M.LabelProp(5, 32, 0.0)
+    sd = {k[2:]: _t(kat[k]) for k in kat.files if k.startswith("p/")}
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    with torch.no_grad():
+        y = net(_t(kat["x"]).to(DEV))
+    close(y, _t(kat["logits"]), "labelprop logits")
+    ref = _t(kat["logits"])
+    top2 = torch.topk(ref, 2, dim=1)[0]
+    near = np.nonzero(((top2[:, 0] - top2[:, 1]) < 1e-4).numpy().reshape(-1))[0]
+    check_mask(torch.max(y, 1)[1], kat["argmax"], near, "labelprop mask")
+    with pytest.raises(Exception):
+        net.train()
+        net(_t(kat["x"]).to(DEV))
