@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const 
   if (a.in_c && a.in_mode != RCV_LOAD_PLAIN && a.in_mode != RCV_LOAD_NCHW)
     for (int e = tid; e < 5 * a.Cin; e += NT) cl[e] = a.in_c[e];
 
-  const TileInfo ti = decode_tile<KIND>(a, blockIdx.x, COT);
+  const TileInfo ti = decode_tile<KIND>(a, xcd_remap(blockIdx.x, a.total_tiles), COT);
   int nxt = 3, ntaps = 9;
   if (KIND == KIND_TPHASE) { nxt = 1 + ti.px; ntaps = (1 + ti.py) * nxt; }
   if (KIND == KIND_TMERGED) { nxt = 2; ntaps = 4; }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   if (a.in_c && a.in_mode != RCV_LOAD_PLAIN && a.in_mode != RCV_LOAD_NCHW)
     for (int e = tid; e < 5 * a.Cin; e += NT) cl[e] = a.in_c[e];
 
-  const TileInfo ti = decode_tile<KIND>(a, blockIdx.x, COT);
+  const TileInfo ti = decode_tile<KIND>(a, xcd_remap(blockIdx.x, a.total_tiles), COT);
   int nxt = 3, ntaps = 9;
   if (KIND == KIND_TPHASE) { nxt = 1 + ti.px; ntaps = (1 + ti.py) * nxt; }
   if (KIND == KIND_TMERGED) { nxt = 2; ntaps = 4; }

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
 
   const int IS = KIND == KIND_GATHER ? a.stride : 1;
   const int aoff = l4 * WS + l15;
-  int tile = blockIdx.x;
+  int tile = xcd_remap(blockIdx.x, gridDim.x);     // neighbouring tiles (shared halo rows) stay on one XCD
   if (tile < a.total_tiles) prefetch(tile);
 
   while (tile < a.total_tiles) {

@@ -44,6 +44,15 @@ static inline FastDiv make_fastdiv(uint32_t d) {
 __device__ __forceinline__ uint32_t fd_div(uint32_t n, FastDiv f) {
   return f.d == 1 ? n : __umulhi(n, f.m);
 }
+// XCD-aware work mapping (MI355X: 8 XCDs, private 4 MiB L2 each; workgroups are dealt round-robin, so ids b and
+// b+8 share an L2).  Maps dispatch id b to a logical id such that every XCD owns one CONTIGUOUS range of logical
+// ids: workgroups that share operands (parity phases / channel tiles of one pixel tile, halo neighbours) then hit in
+// the same L2.  Bijective for any n (cdna guide T1).  Affects speed only.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int xcd = b & 7, i = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
 #endif
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

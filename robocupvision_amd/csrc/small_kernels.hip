@@ -231,8 +231,23 @@ __global__ void cls_bwd_kernel(const float* __restrict__ up, const float* __rest
       for (int c = 0; c < COUT; ++c) acc = fmaf(g[c], ws[c * CIN + k], acc);
       d[k] = acc;
     }
+    if (CIN == 8 && (total & 63) == 0) {
+      // a lane holds its pixel's 8 floats (32 B).  Store s (0|1) writes the 1 KiB of pixels 32s..32s+31 of the wave:
+      // lane l sends float4 (l&1) of pixel 32s + (l>>1), fetched from that lane by shuffles => whole-line stores.
+      const int lane = threadIdx.x & 63;
+      const size_t wave_p0 = p - lane;
 #pragma unroll
-    for (int q = 0; q < CIN / 4; ++q) sst4(dup + p * CIN + 4 * q, make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]));
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const int src = sidx * 32 + (lane >> 1);
+        float4 lo, hi;
+        lo.x = __shfl(d[0], src); lo.y = __shfl(d[1], src); lo.z = __shfl(d[2], src); lo.w = __shfl(d[3], src);
+        hi.x = __shfl(d[4], src); hi.y = __shfl(d[5], src); hi.z = __shfl(d[6], src); hi.w = __shfl(d[7], src);
+        sst4(dup + (wave_p0 + sidx * 32) * CIN + lane * 4, (lane & 1) ? hi : lo);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < CIN / 4; ++q) sst4(dup + p * CIN + 4 * q, make_float4(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]));
+    }
 #pragma unroll
     for (int c = 0; c < COUT; ++c) {
       db[c] += g[c];

@@ -34,7 +34,7 @@ struct WgradArgs {
   int N, H, W, Hp, Wp, CA, CB, CAP, CBP;
   int stride, dil;
   int R, Wt, Wt4, tiles_x, tiles_y, ntiles, IH, IW, SP, SG;
-  int nsplit;
+  int nsplit, nctiles;
   int pl_floats, gl_floats;      // LDS carve: P tile, G tile (then the load constants)
   FastDiv fdWt4, fdIW;
 };
@@ -98,8 +98,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
   const int wave_m = wave / (WAVES_K * WAVES_N);
   const int l15 = lane & 15, l4 = lane >> 4;
 
+  // 1-D grid, channel tile fastest: the channel tiles of one pixel split run side by side on ONE XCD and share its L2
   const int n_ca_tiles = FOLD ? 1 : (a.CAP + CAT - 1) / CAT;
-  const int cb_tile = blockIdx.y / n_ca_tiles, ca_tile = blockIdx.y % n_ca_tiles;
+  const int bl = xcd_remap(blockIdx.x, gridDim.x);
+  const int ctile = bl % a.nctiles, split = bl / a.nctiles;
+  const int cb_tile = ctile / n_ca_tiles, ca_tile = ctile % n_ca_tiles;
   const int cb0 = cb_tile * CBT, ca0 = ca_tile * CAT;
   const int s = a.stride, d = a.dil;
   const int QG = FOLD ? (a.CA + 3) / 4 : CAT / 4;        // 16-byte quads per staged gathered pixel
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
   const int ksteps = np_pix / 4;
   const int a_lane = l4 * a.SP + (wave_m * WM) * 16 + l15;
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += a.nsplit) {
+  for (int tile = split; tile < a.ntiles; tile += a.nsplit) {
     __syncthreads();                  // previous MFMA phase is done with the tiles (and the constants are in place)
     stage(tile);
     __syncthreads();
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int cb = cb0 + (wave_m * WM + m) * 16 + 4 * l4 + r;
-          if (cb < a.CBP && ca < a.CAP) a.part[(((size_t)blockIdx.x * 9 + tap) * a.CBP + cb) * a.CAP + ca] = acc[t][m][r];
+          if (cb < a.CBP && ca < a.CAP) a.part[(((size_t)split * 9 + tap) * a.CBP + cb) * a.CAP + ca] = acc[t][m][r];
         }
     }
   }
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
       float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int e = tid; e < NT; e += QP) { const float4 v = sb[e]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
       const int cb = cb0 + 4 * tid;
-      if (cb < a.CBP) *reinterpret_cast<float4*>(a.part_bias + (size_t)blockIdx.x * a.CBP + cb) = u;
+      if (cb < a.CBP) *reinterpret_cast<float4*>(a.part_bias + (size_t)split * a.CBP + cb) = u;
     }
   }
 }
@@ -426,7 +429,7 @@ static int wlaunch_inst(const WgradArgs& a, bool gtwo, dim3 grid, size_t lds, hi
   return RCV_OK;
 }
 
-struct WPlan { int tile; int R, Wt, Wt4, tiles_x, tiles_y, IH, IW, SP, SG, nsplit, pl_floats, gl_floats; size_t lds; dim3 grid; int CAP, CBP; };
+struct WPlan { int nctiles; int tile; int R, Wt, Wt4, tiles_x, tiles_y, IH, IW, SP, SG, nsplit, pl_floats, gl_floats; size_t lds; dim3 grid; int CAP, CBP; };
 
 static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   const int N = op->i[RCV_I_N], H = op->i[RCV_I_H], W = op->i[RCV_I_W];
@@ -499,7 +502,8 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   if (nsplit > ntiles) nsplit = ntiles;
   nsplit = ceil_div(ntiles, ceil_div(ntiles, nsplit));      // equal tile counts per workgroup
   pl->nsplit = nsplit;
-  pl->grid = dim3(nsplit, ctiles, 1);
+  pl->grid = dim3(nsplit * ctiles, 1, 1);
+  pl->nctiles = ctiles;
   return RCV_OK;
 }
 
@@ -539,7 +543,7 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   a.stride = op->i[RCV_I_STRIDE]; a.dil = op->i[RCV_I_DIL];
   a.R = pl.R; a.Wt = pl.Wt; a.Wt4 = pl.Wt4; a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
   a.ntiles = a.N * pl.tiles_x * pl.tiles_y; a.IH = pl.IH; a.IW = pl.IW; a.SP = pl.SP; a.SG = pl.SG;
-  a.nsplit = pl.nsplit; a.pl_floats = pl.pl_floats; a.gl_floats = pl.gl_floats;
+  a.nsplit = pl.nsplit; a.nctiles = pl.nctiles; a.pl_floats = pl.pl_floats; a.gl_floats = pl.gl_floats;
   a.fdWt4 = make_fastdiv(pl.Wt4); a.fdIW = make_fastdiv(pl.IW);
   RCV_CHECK_ARG(a.g && a.p && a.part, "wgrad: null operand");
   RCV_CHECK_ARG(op->i[RCV_I_NSPLIT] == pl.nsplit, "wgrad: workspace splits %d != %d", op->i[RCV_I_NSPLIT], pl.nsplit);
