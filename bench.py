@@ -43,6 +43,40 @@ def synthetic(B, H, W, seed):
     return x, t
 
 
+def pmc_traffic(label):
+    """HBM bytes per launch of the kernel family `label` from the newest committed PMC pass (profiles/*_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command, corrected as MI355X_MICROARCH.md
+    prescribes); None when no pass is on disk."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+    if not files:
+        return None, None
+    kern = json.load(open(files[-1]))["kernels"]
+    m = re.match(r"(t?conv)(m?)(s?)_(mfma|dma)<([0-9,]+)>|(wgrad)_mfma<([0-9,]+),f(\d+)>", label)
+    if not m:
+        return None, None
+    if m.group(6):
+        base, nums = "wgrad_mfma_kernel", m.group(7).split(",") + [m.group(8)]
+        want = lambda k: k.startswith(base + "<") and [x.strip() for x in k[len(base) + 1:-1].split(",")][:6] == nums
+    else:
+        nums = m.group(5).split(",")
+        base = "convs_mfma_kernel" if m.group(3) else ("conv_dma_kernel" if m.group(4) == "dma" else "conv_mfma_kernel")
+        kind = "2" if m.group(2) else ("1" if m.group(1) == "tconv" else "0")
+        if m.group(3):      # convs_mfma_kernel<WM, WN, CK, KIND, XMAX, TWO>
+            want = lambda k: k.startswith(base + "<") and [x.strip() for x in k[len(base) + 1:-1].split(",")][:4] == nums[:3] + [kind]
+        elif m.group(4) == "dma":   # conv_dma_kernel<WM, WN, WAVES_M, WAVES_N, KIND, TWO>
+            want = lambda k: k.startswith(base + "<") and [x.strip() for x in k[len(base) + 1:-1].split(",")][:5] == nums[:4] + [kind]
+        else:               # conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, CK, KIND>
+            want = lambda k: k.startswith(base + "<") and [x.strip() for x in k[len(base) + 1:-1].split(",")][:6] == nums[:5] + [kind]
+    tot, n = 0.0, 0
+    for k, v in kern.items():
+        if want(k):
+            tot += v["hbm_bytes_per_launch"] * v["launches"]
+            n += v["launches"]
+    return (tot / n if n else None), os.path.basename(files[-1])
+
+
 def cpu_baseline(ctor, H, W, budget_s=20.0):
     """The CPU oracle on this host: same step body, all host threads, bounded sample."""
     from oracle import cpu_reference as O
@@ -163,6 +197,11 @@ def main():
                            "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                            "share_of_kernel_time": round(d["ms"] / total_ms, 4),
                            "algorithmic_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1) if d["ms"] > 0 else 0.0}
+        tr, src = pmc_traffic(dom)
+        if tr is not None:
+            out["roofline"]["traffic"] = int(tr)
+            out["roofline"]["traffic_source"] = "profiles/" + src
+            out["roofline"]["algorithmic_bytes_per_launch"] = int(d["bytes"] / d["launches"])
         mf = sum(a["flops"] for a in by.values())
         out["roofline"]["step_tflops"] = round(mf / (total_ms * 1e-3) / 1e12, 3)
         out["roofline"]["sum_kernel_ms"] = round(total_ms, 4)

@@ -199,7 +199,7 @@ __global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restr
 // classifier backward: d_up[p][k] = sum_c dl[c][p] W[c][k];  dW[c][k] = sum_p dl[c][p] up[p][k];
 // db[c] = sum_p dl[c][p];  optional decoder BN-backward statistics of d_up against t.
 template <int CIN, int COUT>
-__global__ void cls_bwd_kernel(const float* __restrict__ up, const float* __restrict__ dl, const float* __restrict__ w,
+__global__ __launch_bounds__(256, 2) void cls_bwd_kernel(const float* __restrict__ up, const float* __restrict__ dl, const float* __restrict__ w,
                                float* __restrict__ dup, const float* __restrict__ t, const float* __restrict__ tc,
                                float* __restrict__ stat_part, float* __restrict__ w_part, int N, int HW, int stats) {
   __shared__ float ws[COUT * CIN];

@@ -244,6 +244,8 @@ class Engine:
         def emit_bn_forward(node: _Node, bn, conv_op: L.RcvOp, Cc: int, Ho: int, Wo: int):
             """Statistics partials of conv_op -> constants (training) or running stats -> constants (eval)."""
             if training:
+                if N * Ho * Wo <= 1:      # same refusal (and text) as torch.nn.functional.batch_norm, which the reference runs
+                    raise ValueError("Expected more than 1 value per channel when training, got input size %s" % ((N, Cc, Ho, Wo),))
                 conv_op.i[L.RCV_I_STATS] = L.STATS_FWD
                 self._workspace(plan, conv_op)
                 fwd.append(conv_op)

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_TAG/{stats,fetch,write} (scripts/profile_round.sh) -> profiles/TAG_kernel_stats.csv,
+profiles/TAG_hbm_traffic.json.  PMC units and the gfx950 correction follow MI355X_MICROARCH.md (section HBM):
+FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE counts a wide (16 B/lane) coalesced read at half its bytes => x2."""
+import collections, csv, glob, json, re, shutil, sys
+tag = sys.argv[1]
+base = "gpurun_out/prof_%s" % tag
+
+
+def kname(n):
+    n = re.sub(r"^void ", "", n)
+    return re.sub(r"\(.*", "", n)
+
+
+def agg(path, counter):
+    d = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            k = kname(r["Kernel_Name"])
+            d[k][0] += float(r["Counter_Value"]); d[k][1] += 1
+    return d
+
+
+f = agg(glob.glob(base + "/fetch/runc/*_counter_collection.csv")[0], "FETCH_SIZE")
+w = agg(glob.glob(base + "/write/runc/*_counter_collection.csv")[0], "WRITE_SIZE")
+out = {}
+for k in sorted(f, key=lambda k: -f[k][0]):
+    fs, n = f[k]
+    ws = w.get(k, [0, 0])[0]
+    out[k] = {"launches": n, "fetch_kib_raw_per_launch": round(fs / n, 1), "write_kib_per_launch": round(ws / max(n, 1), 1),
+              "hbm_bytes_per_launch": int((2 * fs + ws) * 1024 / n)}
+json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 5 --warmup 2`; "
+                   "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches (gfx950 half-count correction on reads)",
+           "kernels": out}, open("profiles/%s_hbm_traffic.json" % tag, "w"), indent=1)
+shutil.copy(glob.glob(base + "/stats/runc/*_kernel_stats.csv")[0], "profiles/%s_kernel_stats.csv" % tag)
+shutil.copy(base + "/bench_stats.json", "profiles/%s_bench_under_rocprof.json" % tag)
+for k, v in list(out.items())[:8]:
+    print("%-58s n=%3d %9.1f MB/launch" % (k[:58], v["launches"], v["hbm_bytes_per_launch"] / 1e6))

@@ -232,3 +232,43 @@ def test_labelprop_inference_vs_golden():
     with pytest.raises(Exception):
         net.train()
         net(_t(kat["x"]).to(DEV))
+
+
+@pytest.mark.parametrize("ctor,B,H,W", [
+    (dict(noScale=True), 2, 32, 48),                       # 2x3 planes at the bottom of the 5-level net
+    (dict(noScale=True), 2, 80, 112),                      # tiles that do not divide the planes
+    (dict(noScale=False), 5, 24, 200),                     # odd batch, very wide / short planes
+    (dict(noScale=False, levels=3, bellySize=0, pool=True), 3, 56, 72),   # U-Net (max-pool) on ragged tiles
+])
+def test_ragged_shapes_vs_oracle(ctor, B, H, W):
+    """Edge shapes (partial tiles, 1-pixel planes, odd batches) against the CPU oracle on the box."""
+    cfg = O.NetConfig(**ctor)
+    torch.manual_seed(12345678)
+    model = M.ROBO_UNet(**ctor)
+    st = O.TrainState(model.state_dict(), cfg)
+    x, t = O.synthetic_batch(B, H, W, seed=11)
+    ref = O.train_step(st, x, t, do_step=False)
+    res = hip_step(model.to(DEV), x.to(DEV), t.to(DEV), do_step=False)
+    close(res["pred"], ref["pred"], "logits vs oracle %s" % ((B, H, W),))
+    assert abs(res["ce"] - ref["ce"]) <= 1e-3 * abs(ref["ce"])
+    margin = torch.topk(ref["pred"], 2, dim=1)[0]
+    near = np.nonzero(((margin[:, 0] - margin[:, 1]) < 1e-4).numpy().reshape(-1))[0]
+    check_mask(res["pc"], ref["pred_class"].numpy().astype(np.uint8), near, "mask vs oracle")
+    for n in st.names:
+        if n.startswith("upPart") and n.endswith("conv.bias"):
+            continue
+        # BatchNorm over the few hundred values of these small planes makes single channels ill-conditioned in fp32 (on
+        # both sides), so judge every tensor as a whole: relative L2 error 5e-3 (an indexing error would be O(1))
+        g, r = res["grads"][n].double().cpu(), st.sd[n].grad.double()
+        rel = float((g - r).norm() / (r.norm() + 1e-30))
+        assert rel <= 5e-3, "grad %s vs oracle: relative L2 error %.3e" % (n, rel)
+
+
+def test_single_value_batchnorm_raises_like_the_reference():
+    """Train-mode BatchNorm over ONE value per channel: PyTorch (hence the reference) raises ValueError; so do we."""
+    model = M.ROBO_UNet(noScale=True).to(DEV).train()
+    with pytest.raises(ValueError):
+        model(torch.zeros(1, 3, 16, 16, device=DEV))
+    model.eval()
+    with torch.no_grad():
+        assert model(torch.zeros(1, 3, 16, 16, device=DEV)).shape == (1, 5, 16, 16)
