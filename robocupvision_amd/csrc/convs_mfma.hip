@@ -138,7 +138,9 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
   while (tile < a.total_tiles) {
     const TileInfo ti = decode_tile<KIND>(a, tile, COT);
     __syncthreads();                 // every wave is done reading the previous tile (and the filter is in place)
-    if (TWO) {
+    if (a.flags & RCV_F_DBG_NOSTAGE) {
+      // profiling ablation: no LDS writes, no global loads
+    } else if (TWO) {
       if (a.in_mode == RCV_LOAD_GRAD_ENC) narrow_write_x<RCV_LOAD_GRAD_ENC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid);
       else narrow_write_x<RCV_LOAD_GRAD_DEC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid);
     } else {
@@ -150,10 +152,11 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
       }
     }
     const int ntile = tile + gridDim.x;
-    if (ntile < a.total_tiles) prefetch(ntile);      // in flight during the contraction and the stores below
+    if (ntile < a.total_tiles && !(a.flags & RCV_F_DBG_NOSTAGE)) prefetch(ntile);      // in flight during the contraction and the stores below
     __syncthreads();
 
     // ---- contraction
+    if (a.flags & RCV_F_DBG_NOMFMA) { tile = ntile; continue; }      // profiling ablation
     int pixoff[WN];
 #pragma unroll
     for (int b = 0; b < WN; ++b) {

@@ -15,11 +15,11 @@
 //     taps of a 3- or 8-channel operand fill 2 or 5 MFMA column blocks instead of 9 mostly empty ones.
 // Both tiles sit in LDS ([pixel][C + pad]); B is read through a per-lane offset table.
 //
-// Schedule: workgroups are persistent over pixel tiles (a pixel split per workgroup); per tile both operands are
-// staged global -> registers -> LDS with the load transform applied (4 independent 16-byte loads per thread in
-// flight), then the MFMA phase runs; two workgroups per CU overlap one's staging with the other's MFMAs.
-// Workgroups write partial filters [split][tap][cb][ca] that RCV_OP_WGRAD_REDUCE sums in a fixed order (no
-// float atomics => bitwise reproducible gradients).
+// Schedule: workgroups are persistent over a pixel split and WAVE-SPECIALISED: 4 consumer waves run the MFMA
+// phase of tile i out of one LDS buffer while 4 producer waves stage tile i+1 (global -> registers, load
+// transform, -> LDS) into the other; one barrier per tile.  (Without it the staging time simply added to the MFMA
+// time: two co-resident workgroups run in lockstep and overlap nothing.)  Workgroups write partial filters
+// [split][tap][cb][ca] that RCV_OP_WGRAD_REDUCE sums in a fixed order (no float atomics => bitwise reproducible).
 #include <stdlib.h>
 #include "rcv_internal.h"
 
@@ -35,6 +35,7 @@ struct WgradArgs {
   int stride, dil;
   int R, Wt, Wt4, tiles_x, tiles_y, ntiles, IH, IW, SP, SG;
   int nsplit, nctiles;
+  uint32_t dbg;
   int pl_floats, gl_floats;      // LDS carve: P tile, G tile (then the load constants)
   FastDiv fdWt4, fdIW;
 };
@@ -79,9 +80,11 @@ __device__ __forceinline__ float4 wxform_rt(int mode, float4 x, float4 a, const 
 // NBF == 0: regular mode (WN column blocks of 16 gathered channels, 9 taps each)
 // NBF  > 0: folded mode (WN must be 1): NBF column blocks over n = tap*CA + ca
 // GTWO: the gathered operand is a two-tensor gradient load (convT layer); otherwise the pointwise one may be.
-template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, int XP, int XG, bool GTWO>
-__global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_kernel(const WgradArgs a) {
-  constexpr int NT = WAVES_M * WAVES_N * WAVES_K * 64;
+template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, bool SPEC, bool GTWO>
+__global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) void wgrad_mfma_kernel(const WgradArgs a) {
+  constexpr int NTC = WAVES_M * WAVES_N * WAVES_K * 64;   // MFMA (consumer) threads: waves 0..3
+  constexpr int NT = NTC;                                 // staging threads: SPEC ? the next 4 (producer) waves : the same waves
+  static_assert(NTC == 256, "wave layouts are 4 waves");
   constexpr int CBT = WM * WAVES_M * 16;
   constexpr int CAT = WN * WAVES_N * 16;
   constexpr bool FOLD = NBF > 0;
@@ -89,10 +92,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
   constexpr int QP = CBT / 4;
   constexpr int STEPP = NT / QP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* pl = smem;
-  float* gl = smem + a.pl_floats;
+  const int bufsz = a.pl_floats + a.gl_floats;            // two (P, G) tile buffers
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool producer = SPEC && threadIdx.x >= NTC;       // SPEC: staging-only waves
+  const bool consumer = !producer;                        // MFMA waves (SPEC: MFMA-only)
+  const bool stager = !SPEC || producer;
+  const int tid = producer ? (int)threadIdx.x - NTC : (int)threadIdx.x;     // index inside the role
+  const int lane = tid & 63, wave = tid >> 6;
   const int wave_k = wave % WAVES_K;
   const int wave_n = (wave / WAVES_K) % WAVES_N;
   const int wave_m = wave / (WAVES_K * WAVES_N);
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
   const bool g_two = a.g_mode == RCV_LOAD_GRAD_ENC || a.g_mode == RCV_LOAD_GRAD_DEC;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int UNR = 4;
-  auto stage = [&](int tile) {
+  auto stage = [&](int tile, float* pl, float* gl) {
     int t = tile;
     const int tx_i = t % a.tiles_x;
     t /= a.tiles_x;
@@ -262,10 +268,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
   const int ksteps = np_pix / 4;
   const int a_lane = l4 * a.SP + (wave_m * WM) * 16 + l15;
 
-  for (int tile = split; tile < a.ntiles; tile += a.nsplit) {
-    __syncthreads();                  // previous MFMA phase is done with the tiles (and the constants are in place)
-    stage(tile);
-    __syncthreads();
+  auto contract = [&](const float* pl, const float* gl) {
     for (int j = wave_k; j < ksteps; j += WAVES_K) {
       const int p0 = 4 * j;
       const int ty = fd_div(p0, a.fdWt4), tx = p0 - ty * a.Wt4;
@@ -280,6 +283,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
         for (int m = 0; m < WM; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv, acc[t][m], 0, 0, 0);
       }
     }
+  };
+  const bool do_stage = !(a.dbg & RCV_F_DBG_NOSTAGE), do_mfma = !(a.dbg & RCV_F_DBG_NOMFMA);
+  if (SPEC) {
+    // producer waves stage tile i+1 into the other buffer while the consumer waves contract tile i: one barrier per tile
+    if (producer && split < a.ntiles && do_stage) stage(split, smem, smem + a.pl_floats);
+    __syncthreads();
+    int it = 0;
+    for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
+      float* pl = smem + (it & 1) * bufsz;
+      if (producer) {
+        const int next = tile + a.nsplit;
+        if (next < a.ntiles && do_stage) { float* pn = smem + ((it + 1) & 1) * bufsz; stage(next, pn, pn + a.pl_floats); }
+      } else if (do_mfma) {
+        contract(pl, pl + a.pl_floats);
+      }
+      __syncthreads();
+    }
+  } else {
+    // staging-heavy (narrow) tiles: every wave stages, then every wave contracts; two workgroups per CU interleave
+    for (int tile = split; tile < a.ntiles; tile += a.nsplit) {
+      __syncthreads();
+      if (do_stage) stage(tile, smem, smem + a.pl_floats);
+      __syncthreads();
+      if (do_mfma) contract(smem, smem + a.pl_floats);
+    }
   }
 
   // ---- reduce the WAVES_K pixel-slices of the workgroup (fixed order) ----
@@ -288,7 +316,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
     for (int kk = 1; kk < WAVES_K; ++kk) {
       __syncthreads();
       float* sc = smem + (wave_m * WAVES_N + wave_n) * PER_WAVE;
-      if (wave_k == kk) {
+      if (consumer && wave_k == kk) {
 #pragma unroll
         for (int t = 0; t < NACC; ++t)
 #pragma unroll
@@ -297,7 +325,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
             for (int r = 0; r < 4; ++r) sc[((t * WM + m) * 4 + r) * 64 + lane] = acc[t][m][r];
       }
       __syncthreads();
-      if (wave_k == 0) {
+      if (consumer && wave_k == 0) {
 #pragma unroll
         for (int t = 0; t < NACC; ++t)
 #pragma unroll
@@ -307,7 +335,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
       }
     }
   }
-  if (wave_k == 0) {
+  if (consumer && wave_k == 0) {
 #pragma unroll
     for (int t = 0; t < NACC; ++t) {
       int tap, ca;
@@ -332,9 +360,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void wgrad_mfma_ker
   if (a.part_bias && ca_tile == 0) {
     __syncthreads();
     float4* sb = reinterpret_cast<float4*>(smem);
-    sb[tid] = bsum;
+    if (stager) sb[tid] = bsum;            // the staging threads summed the pointwise operand
     __syncthreads();
-    if (tid < QP) {
+    if (stager && tid < QP) {
       float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int e = tid; e < NT; e += QP) { const float4 v = sb[e]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
       const int cb = cb0 + 4 * tid;
@@ -387,29 +415,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // host side
 // --------------------------------------------------------------------------------------------
 struct WTile {
-  int WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, XP, XG;
+  int WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, SPEC;
   int cbt() const { return WM * WAVES_M * 16; }
   int cat() const { return WN * WAVES_N * 16; }
-  int nt() const { return WAVES_M * WAVES_N * WAVES_K * 64; }
+  int nt() const { return 256; }      // staging threads
 };
 static const WTile kWT[] = {
-    {2, 2, 2, 2, 1, 0, 6, 16},  // 0: 64 x 64
-    {2, 2, 2, 1, 2, 0, 6, 8},   // 1: 64 x 32
-    {2, 2, 1, 2, 2, 0, 8, 12},  // 2: 32 x 64
-    {2, 2, 1, 1, 4, 0, 8, 8},   // 3: 32 x 32
-    {2, 1, 1, 1, 4, 0, 8, 8},   // 4: 32 x 16
-    {1, 2, 1, 1, 4, 0, 8, 8},   // 5: 16 x 32
-    {1, 1, 1, 1, 4, 0, 8, 8},   // 6: 16 x 16
-    {1, 1, 1, 1, 4, 2, 8, 8},   // 7: 16 x (9 taps x <=3 ch folded into 2 blocks)
-    {1, 1, 1, 1, 4, 5, 8, 8},   // 8: 16 x (9 taps x <=8 ch folded into 5 blocks)
+    {2, 2, 2, 2, 1, 0, 1},  // 0: 64 x 64, producer/consumer waves
+    {2, 2, 2, 1, 2, 0, 1},  // 1: 64 x 32
+    {2, 2, 1, 2, 2, 0, 1},  // 2: 32 x 64
+    {2, 2, 1, 1, 4, 0, 1},  // 3: 32 x 32
+    {2, 1, 1, 1, 4, 0, 0},  // 4: 32 x 16, shared roles (staging heavy)
+    {1, 2, 1, 1, 4, 0, 0},  // 5: 16 x 32
+    {1, 1, 1, 1, 4, 0, 0},  // 6: 16 x 16
+    {1, 1, 1, 1, 4, 2, 0},  // 7: 16 x (9 taps x <=3 ch folded into 2 blocks)
+    {1, 1, 1, 1, 4, 5, 0},  // 8: 16 x (9 taps x <=8 ch folded into 5 blocks)
 };
 static const int kNumWT = sizeof(kWT) / sizeof(kWT[0]);
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, int XP, int XG>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, bool SPEC>
 static int wlaunch_inst(const WgradArgs& a, bool gtwo, dim3 grid, size_t lds, hipStream_t s) {
-  constexpr int NT = WAVES_M * WAVES_N * WAVES_K * 64;
+  constexpr int NT = WAVES_M * WAVES_N * WAVES_K * 64 + (SPEC ? 256 : 0);     // consumer (+ producer) waves
   if (gtwo) {
-    auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, XP, XG, true>;
+    auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, SPEC, true>;
     static size_t configured = 0;
     if (lds > configured) {
       RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -417,7 +445,7 @@ static int wlaunch_inst(const WgradArgs& a, bool gtwo, dim3 grid, size_t lds, hi
     }
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, a);
   } else {
-    auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, XP, XG, false>;
+    auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, SPEC, false>;
     static size_t configured = 0;
     if (lds > configured) {
       RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -463,14 +491,14 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   if (fold) pl->SG = 4 * QG + 1;
   else pl->SG = s == 1 ? (wt.cat() % 32 == 0 ? wt.cat() + 16 : wt.cat()) : wt.cat() + 8;
   // pixel tile: widest row segment, then as many rows as the prefetch registers and the LDS budget allow
-  const size_t budget = 80 * 1024 / sizeof(float);   // two workgroups per CU
+  const size_t budget = (wt.SPEC ? 78 : 80) * 1024 / sizeof(float);   // SPEC: per buffer (two buffers, one workgroup per CU); else two workgroups per CU
   int bestR = 0, bestWt = 0;
   for (int nx = 1; nx <= Wp && bestR == 0; ++nx) {
     const int Wt = ceil_div(Wp, nx), Wt4 = round_up(Wt, 4);
     const int IW = (Wt4 - 1) * s + 2 * d + 1;
     for (int R = Hp; R >= 1; --R) {
       const int IH = (R - 1) * s + 2 * d + 1;
-      if (R * Wt4 > 640 || IH * IW >= 65536) continue;
+      if (R * Wt4 > (wt.SPEC ? 1024 : 640) || IH * IW >= 65536) continue;
       if ((size_t)R * Wt4 * pl->SP + (size_t)IH * IW * pl->SG > budget) continue;
       bestR = R; bestWt = Wt;
       break;
@@ -483,7 +511,7 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   pl->tiles_x = ceil_div(Wp, bestWt); pl->tiles_y = ceil_div(Hp, R);
   pl->pl_floats = round_up(R * Wt4 * pl->SP, 4);
   pl->gl_floats = round_up(pl->IH * pl->IW * pl->SG, 4);
-  size_t floats = (size_t)pl->pl_floats + pl->gl_floats;
+  size_t floats = (wt.SPEC ? 2 : 1) * ((size_t)pl->pl_floats + pl->gl_floats);
   const int nacc = wt.NBF ? wt.NBF : 9 * wt.WN;
   const size_t red = (size_t)wt.WAVES_M * wt.WAVES_N * nacc * wt.WM * 4 * 64;
   if (wt.WAVES_K > 1 && floats < red) floats = red;
@@ -493,9 +521,7 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   RCV_CHECK_ARG(pl->lds <= (size_t)h->max_lds, "wgrad: tile needs %zu B of LDS (limit %d)", pl->lds, h->max_lds);
   const int ctiles = ceil_div(pl->CBP, wt.cbt()) * (fold ? 1 : ceil_div(pl->CAP, wt.cat()));
   const int ntiles = N * pl->tiles_x * pl->tiles_y;
-  int per_cu = (int)((size_t)h->max_lds / pl->lds);
-  if (per_cu > 2) per_cu = 2;
-  if (per_cu < 1) per_cu = 1;
+  int per_cu = wt.SPEC ? 1 : 2;                     // SPEC: 512 threads with > 128 registers => one workgroup per CU
   if (const char* ev = getenv("RCV_WGRAD_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4) per_cu = o; }
   int nsplit = (per_cu * h->num_cus) / ctiles;
   if (nsplit < 1) nsplit = 1;
@@ -543,7 +569,7 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   a.stride = op->i[RCV_I_STRIDE]; a.dil = op->i[RCV_I_DIL];
   a.R = pl.R; a.Wt = pl.Wt; a.Wt4 = pl.Wt4; a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y;
   a.ntiles = a.N * pl.tiles_x * pl.tiles_y; a.IH = pl.IH; a.IW = pl.IW; a.SP = pl.SP; a.SG = pl.SG;
-  a.nsplit = pl.nsplit; a.nctiles = pl.nctiles; a.pl_floats = pl.pl_floats; a.gl_floats = pl.gl_floats;
+  a.dbg = op->flags; a.nsplit = pl.nsplit; a.nctiles = pl.nctiles; a.pl_floats = pl.pl_floats; a.gl_floats = pl.gl_floats;
   a.fdWt4 = make_fastdiv(pl.Wt4); a.fdIW = make_fastdiv(pl.IW);
   RCV_CHECK_ARG(a.g && a.p && a.part, "wgrad: null operand");
   RCV_CHECK_ARG(op->i[RCV_I_NSPLIT] == pl.nsplit, "wgrad: workspace splits %d != %d", op->i[RCV_I_NSPLIT], pl.nsplit);
@@ -557,14 +583,14 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   RCV_CHECK_ARG(!p_two || a.p_aux, "wgrad: pointwise gradient load needs aux");
   a.part_bias = (op->flags & RCV_F_BIAS) ? a.part + (size_t)pl.nsplit * 9 * pl.CBP * pl.CAP : nullptr;
   switch (pl.tile) {
-    case 0: return wlaunch_inst<2, 2, 2, 2, 1, 0, 6, 16>(a, g_two, pl.grid, pl.lds, s);
-    case 1: return wlaunch_inst<2, 2, 2, 1, 2, 0, 6, 8>(a, g_two, pl.grid, pl.lds, s);
-    case 2: return wlaunch_inst<2, 2, 1, 2, 2, 0, 8, 12>(a, g_two, pl.grid, pl.lds, s);
-    case 3: return wlaunch_inst<2, 2, 1, 1, 4, 0, 8, 8>(a, g_two, pl.grid, pl.lds, s);
-    case 4: return wlaunch_inst<2, 1, 1, 1, 4, 0, 8, 8>(a, g_two, pl.grid, pl.lds, s);
-    case 5: return wlaunch_inst<1, 2, 1, 1, 4, 0, 8, 8>(a, g_two, pl.grid, pl.lds, s);
-    case 6: return wlaunch_inst<1, 1, 1, 1, 4, 0, 8, 8>(a, g_two, pl.grid, pl.lds, s);
-    case 7: return wlaunch_inst<1, 1, 1, 1, 4, 2, 8, 8>(a, g_two, pl.grid, pl.lds, s);
-    default: return wlaunch_inst<1, 1, 1, 1, 4, 5, 8, 8>(a, g_two, pl.grid, pl.lds, s);
+    case 0: return wlaunch_inst<2, 2, 2, 2, 1, 0, true>(a, g_two, pl.grid, pl.lds, s);
+    case 1: return wlaunch_inst<2, 2, 2, 1, 2, 0, true>(a, g_two, pl.grid, pl.lds, s);
+    case 2: return wlaunch_inst<2, 2, 1, 2, 2, 0, true>(a, g_two, pl.grid, pl.lds, s);
+    case 3: return wlaunch_inst<2, 2, 1, 1, 4, 0, true>(a, g_two, pl.grid, pl.lds, s);
+    case 4: return wlaunch_inst<2, 1, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s);
+    case 5: return wlaunch_inst<1, 2, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s);
+    case 6: return wlaunch_inst<1, 1, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s);
+    case 7: return wlaunch_inst<1, 1, 1, 1, 4, 2, false>(a, g_two, pl.grid, pl.lds, s);
+    default: return wlaunch_inst<1, 1, 1, 1, 4, 5, false>(a, g_two, pl.grid, pl.lds, s);
   }
 }
