@@ -205,6 +205,12 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
         if (a.stats == RCV_STATS_BWD_DEC) { e0 = ld4(a.epi_c + co); e1 = ld4(a.epi_c + a.Cout + co); }
         if (a.stats == RCV_STATS_BWD_DEC || a.stats == RCV_STATS_BWD_ENC) mu = ld4(a.epi_c + 2 * a.Cout + co);
       }
+      // first every load of the skip gradient / statistics operand of this co-block (independent, in flight together),
+      // then the arithmetic and the stores
+      size_t offs[WN];
+      bool oks[WN];
+      float4 rr[WN], ee[WN];
+      const bool need_e = a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC;
 #pragma unroll
       for (int b = 0; b < WN; ++b) {
         const int p = (wave * WN + b) * 16 + l15;
@@ -217,23 +223,32 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
         } else {
           ok = ok && oy < a.Ho && ox < a.Wo;
         }
-        if (!ok) continue;
-        const size_t off = ((size_t)(ti.n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+        oks[b] = ok;
+        offs[b] = ((size_t)(ti.n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+        rr[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ee[b] = rr[b];
+        if (ok) {
+          if (a.flags & RCV_F_RESID) rr[b] = ld4(a.resid + offs[b]);
+          if (need_e) ee[b] = ld4(a.epi_aux + offs[b]);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < WN; ++b) {
+        if (!oks[b]) continue;
         float4 v = make_float4(acc[m][b][0] + bias.x, acc[m][b][1] + bias.y, acc[m][b][2] + bias.z, acc[m][b][3] + bias.w);
         if (a.flags & RCV_F_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (a.flags & RCV_F_RESID) { const float4 rr = ld4(a.resid + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-        *reinterpret_cast<float4*>(a.out + off) = v;
+        v.x += rr[b].x; v.y += rr[b].y; v.z += rr[b].z; v.w += rr[b].w;
+        *reinterpret_cast<float4*>(a.out + offs[b]) = v;
+        const float4 e = ee[b];
         if (a.stats == RCV_STATS_FWD) {
           s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
           s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
           s2[m][2] = fmaf(v.z, v.z, s2[m][2]); s2[m][3] = fmaf(v.w, v.w, s2[m][3]);
         } else if (a.stats == RCV_STATS_BWD_ENC) {
-          const float4 e = ld4(a.epi_aux + off);
           s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
           s2[m][0] = fmaf(v.x, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(v.y, e.y - mu.y, s2[m][1]);
           s2[m][2] = fmaf(v.z, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(v.w, e.w - mu.w, s2[m][3]);
         } else if (a.stats == RCV_STATS_BWD_DEC) {
-          const float4 e = ld4(a.epi_aux + off);
           const float gx = fmaf(e.x, e0.x, e1.x) > 0.f ? v.x : 0.f;
           const float gy = fmaf(e.y, e0.y, e1.y) > 0.f ? v.y : 0.f;
           const float gz = fmaf(e.z, e0.z, e1.z) > 0.f ? v.z : 0.f;
