@@ -78,7 +78,8 @@ enum {
   RCV_OP_CONV1X1     = 18, /* generic 1x1 convolution NHWC -> NHWC/NCHW (LabelProp classifier)   */
   RCV_OP_ADD_SLICE   = 19, /* x[..., 0:Ca] += affine(a)   (LabelProp top skip, model.py:565)     */
   RCV_OP_MATERIALIZE = 20, /* out = load(in)  (a block's normalised output as a plain tensor)    */
-  RCV_OP_BWD_STATS   = 21  /* out = g; partial rows of the BN-backward sums of g against e       */
+  RCV_OP_BWD_STATS   = 21, /* out = g; partial rows of the BN-backward sums of g against e       */
+  RCV_OP_CONFUSION   = 22  /* counts[n][pred][label] += 1 per pixel (int32, accumulating)            */
 };
 
 /* how an operand is produced from memory while it is staged (rcv_op.i[RCV_I_INMODE] etc.) */
@@ -225,6 +226,11 @@ int rcv_softmax_ce_bwd(rcv_handle* h, const float* logits, const int64_t* target
 
 /* train.py:23-27,52-55 (decay * L1 -> gradient decay*sign(p)) + torch.optim.Adam.step            *
  * (train.py:67,357-363) over one flat fp32 buffer; lr is per element group via lr_scale[].      */
+/* Per-image confusion matrices from the arg-max mask (uint8) and the labels (int64): replaces the Python
+ * mask loops of valid() (train.py:136-153).  counts is int32 [N][C][C] indexed [n][pred][label]; the call ADDS.   */
+int rcv_confusion(rcv_handle* h, const uint8_t* argmax, const int64_t* target, int N, int C, int H, int W,
+                  int32_t* counts, void* stream);
+
 int rcv_adam_l1_step(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                      const float* lr_elem /*may be NULL*/, int64_t n, float lr, float beta1, float beta2,
                      float eps, float decay, int step, float grad_scale, void* stream);

@@ -197,6 +197,15 @@ int rcv_softmax_ce_bwd(rcv_handle* h, const float* logits, const int64_t* target
   return rcv_run(h, &op, 1, stream);
 }
 
+int rcv_confusion(rcv_handle* h, const uint8_t* argmax, const int64_t* target, int N, int C, int H, int W, int32_t* counts, void* stream) {
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_CONFUSION;
+  op.i[RCV_I_N] = N; op.i[RCV_I_H] = H; op.i[RCV_I_W] = W; op.i[RCV_I_COUT] = C;
+  op.p[RCV_P_IN] = (void*)argmax; op.p[RCV_P_IN2] = (void*)target; op.p[RCV_P_OUT] = counts;
+  return rcv_run(h, &op, 1, stream);
+}
+
 int rcv_adam_l1_step(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* lr_elem,
                      int64_t n, float lr, float beta1, float beta2, float eps, float decay, int step, float grad_scale,
                      void* stream) {

@@ -310,17 +310,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const 
     __syncthreads();
     if (a.flags & RCV_F_DBG_NOMFMA) continue;
     // ---- contraction over (tap, ci in chunk)
-    for (int j = 0; j < ntaps; ++j) {
-      int dy, dx;
-      const int jy = j / nxt, jx = j - jy * nxt;
-      if (KIND == KIND_TPHASE) {
-        dy = ti.py ? (jy ? 0 : 1) : 0;
-        dx = ti.px ? (jx ? 0 : 1) : 0;
-      } else if (KIND == KIND_TMERGED) {
-        dy = jy; dx = jx;
-      } else {
-        dy = jy * a.dil; dx = jx * a.dil;
-      }
+    auto tap = [&](int j, int dy, int dx) {
       const float* wj = wl + j * CK * WS + aoff;
       const float* xj = xl + (dy * a.IW + dx) * S;
 #pragma unroll
@@ -335,6 +325,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const 
 #pragma unroll
           for (int b = 0; b < WN; ++b)
             acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[m][b], 0, 0, 0);
+      }
+    };
+    if (KIND == KIND_GATHER) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) tap(j, (j / 3) * a.dil, (j % 3) * a.dil);     // compile-time trip count: reads pipeline under MFMAs
+    } else {
+      for (int j = 0; j < ntaps; ++j) {
+        const int jy = j / nxt, jx = j - jy * nxt;
+        if (KIND == KIND_TPHASE) tap(j, ti.py ? (jy ? 0 : 1) : 0, ti.px ? (jx ? 0 : 1) : 0);
+        else tap(j, jy, jx);
       }
     }
   }
@@ -470,31 +470,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
 #pragma unroll
     for (int b = 0; b < WN; ++b) acc[m][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  dma_w(0, 0);
-  load_x(0);
+  const bool dbg_nostage = a.flags & RCV_F_DBG_NOSTAGE, dbg_nomfma = a.flags & RCV_F_DBG_NOMFMA;
+  if (!dbg_nostage) { dma_w(0, 0); load_x(0); }
   const int nchunks = a.CinP / CK;
   for (int i = 0; i < nchunks; ++i) {
     const int buf = i & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces and input loads have landed
-    write_x(buf, i * CK);
+    if (!dbg_nostage) write_x(buf, i * CK);
     __syncthreads();          // everyone's pieces landed and tile written; everyone finished contracting chunk i-1
-    if (i + 1 < nchunks) {
+    if (dbg_nomfma) { if (i + 1 < nchunks && !dbg_nostage) { dma_w(buf ^ 1, (i + 1) * CK); load_x((i + 1) * CK); } continue; }
+    if (i + 1 < nchunks && !dbg_nostage) {
       dma_w(buf ^ 1, (i + 1) * CK);                       // in flight during the contraction below
       load_x((i + 1) * CK);
     }
     const float* wb = wl + buf * WBUF;
     const float* xb = xl + buf * a.xl_floats;
-    for (int j = 0; j < ntaps; ++j) {
-      int dy, dx;
-      const int jy = j / nxt, jx = j - jy * nxt;
-      if (KIND == KIND_TPHASE) {
-        dy = ti.py ? (jy ? 0 : 1) : 0;
-        dx = ti.px ? (jx ? 0 : 1) : 0;
-      } else if (KIND == KIND_TMERGED) {
-        dy = jy; dx = jx;
-      } else {
-        dy = jy * a.dil; dx = jx * a.dil;
-      }
+    auto tap = [&](int j, int dy, int dx) {
       const float* wj = wb + j * CK * WS + aoff;
       const float* xj = xb + (dy * a.IW + dx) * S;
       float av[WM], bv[WN];
@@ -507,6 +498,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
 #pragma unroll
         for (int b = 0; b < WN; ++b)
           acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[m][b], 0, 0, 0);
+    };
+    if (KIND == KIND_GATHER) {
+      // compile-time trip count: the operand reads of tap j+1 are scheduled under the MFMAs of tap j
+#pragma unroll
+      for (int j = 0; j < 9; ++j) tap(j, (j / 3) * a.dil, (j % 3) * a.dil);
+    } else {
+      for (int j = 0; j < ntaps; ++j) {
+        const int jy = j / nxt, jx = j - jy * nxt;
+        if (KIND == KIND_TPHASE) tap(j, ti.py ? (jy ? 0 : 1) : 0, ti.px ? (jx ? 0 : 1) : 0);
+        else tap(j, jy, jx);
+      }
     }
   }
   conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND>(a, ti, acc, red, tid);

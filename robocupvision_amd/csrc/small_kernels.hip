@@ -525,6 +525,23 @@ __global__ void add_slice_kernel(float* __restrict__ x, int C, const float* __re
   }
 }
 
+// counts[n][pred][label] += 1: per-block LDS histogram (integer atomics: order independent), then one global add per bin
+__global__ void confusion_kernel(const uint8_t* __restrict__ pred, const int64_t* __restrict__ target, int* __restrict__ counts,
+                                 int HW, int C) {
+  __shared__ int hist[64];
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int n = blockIdx.y;
+  const uint8_t* pp = pred + (size_t)n * HW;
+  const int64_t* tt = target + (size_t)n * HW;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    const int p = pp[i], t = (int)tt[i];
+    if (p < C && t >= 0 && t < C) atomicAdd(&hist[p * C + t], 1);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < C * C && hist[threadIdx.x]) atomicAdd(&counts[(size_t)n * C * C + threadIdx.x], hist[threadIdx.x]);
+}
+
 // out = f(in): a block's output as a plain NHWC tensor (block-level module calls, LabelProp tail)
 __global__ void materialize_kernel(const float* __restrict__ x, const float* __restrict__ c, float* __restrict__ out, size_t n4, int C,
                                    int mode) {
@@ -601,9 +618,9 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   if (query) {
     static const char* names[] = {"?", "conv", "tconv", "wgrad", "wgrad_reduce", "pack", "bn_finalize", "bn_eval", "bn_bwd", "combine",
                                   "cls_fwd", "cls_bwd", "ce_fwd", "ce_bwd", "pool_fwd", "pool_bwd", "adam_l1", "memset", "conv1x1",
-                                  "add_slice", "materialize", "bwd_stats"};
+                                  "add_slice", "materialize", "bwd_stats", "confusion"};
     query->n_part = 0; query->n_split = 0; query->part_bytes = 0;
-    snprintf(query->label, sizeof(query->label), "%s", (op->kind > 0 && op->kind <= 21) ? names[op->kind] : "?");
+    snprintf(query->label, sizeof(query->label), "%s", (op->kind > 0 && op->kind <= 22) ? names[op->kind] : "?");
   }
   switch (op->kind) {
     case RCV_OP_PACK: {
@@ -782,6 +799,16 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       const size_t npix = (size_t)N * H * W;
       hipLaunchKernelGGL(add_slice_kernel, dim3(stream_grid(h, npix * (Ca / 4), 256)), dim3(256), 0, s, (float*)op->p[RCV_P_OUT], Cout,
                          (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN_C], Ca, npix, op->i[RCV_I_INMODE]);
+      break;
+    }
+    case RCV_OP_CONFUSION: {
+      if (query) return RCV_OK;
+      RCV_CHECK_ARG(Cout >= 1 && Cout <= 8 && N > 0 && H > 0 && W > 0, "confusion: %d classes unsupported (max 8)", Cout);
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_OUT], "confusion: null operand");
+      int gx = ceil_div(H * W, 256 * 8);
+      if (gx > 64) gx = 64;
+      hipLaunchKernelGGL(confusion_kernel, dim3(gx, N), dim3(256), 0, s, (const uint8_t*)op->p[RCV_P_IN], (const int64_t*)op->p[RCV_P_IN2],
+                         (int*)op->p[RCV_P_OUT], H * W, Cout);
       break;
     }
     case RCV_OP_MATERIALIZE: {

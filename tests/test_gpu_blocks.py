@@ -122,3 +122,31 @@ def test_empty_and_bad_shapes_raise():
         m(torch.zeros(1, 3, 20, 24, device=DEV))       # not a multiple of 8
     with pytest.raises(ValueError):
         m(torch.zeros(1, 4, 16, 16, device=DEV))
+
+
+def test_device_metrics_match_reference_loops():
+    """RCV_OP_CONFUSION + SegmentationMetrics against the reference's Python mask loops (train.py:136-163)."""
+    from robocupvision_amd.metrics import SegmentationMetrics
+    g = torch.Generator().manual_seed(3)
+    C, B, H, W = 5, 3, 24, 40
+    pred = torch.randint(0, C, (B, H, W), generator=g)
+    tgt = torch.randint(0, C, (B, H, W), generator=g)
+    tgt[1][tgt[1] == 3] = 0                     # a class absent from one image (union == 0 branch)
+    pred[1][pred[1] == 3] = 1
+    conf = torch.zeros(C, C); iou = torch.zeros(C); lab = torch.zeros(C)
+    for n in range(B):
+        for l in range(C):
+            lab[l] += int((tgt[n] == l).sum())
+            for p_ in range(C):
+                inter = int(((pred[n] == p_) & (tgt[n] == l)).sum())
+                conf[p_, l] += inter
+                if l == p_:
+                    union = int(((pred[n] == p_) | (tgt[n] == l)).sum())
+                    iou[l] += 1 if union == 0 else inter / union
+    ref_cls = sum(float(conf[j, j] / (lab[j] / 100.0)) for j in range(C)) / C
+    ref_iou = float((iou / B).sum()) / C * 100
+    m = SegmentationMetrics(C, DEV)
+    m.update(pred.to(torch.uint8).to(DEV), tgt.to(DEV))
+    out = m.compute()
+    assert abs(out["mean_class_acc"] - ref_cls) < 1e-4 and abs(out["mean_iou"] - ref_iou) < 1e-4      # the loop reference is fp32
+    assert abs(out["pixel_acc"] - float((pred == tgt).sum()) / pred.numel() * 100) < 1e-9
