@@ -33,6 +33,9 @@ WORKLOADS = {
     "robo_unet_160x120_bs64": (dict(noScale=False, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128), 64, 120, 160),
     "unet_640x480_bs32": (dict(noScale=True, planes=8, depth=4, levels=3, bellySize=0, bellyPlanes=128, pool=True), 32, 480, 640),
     "robo_unet_320x240_bs32": (dict(noScale=True, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128), 32, 240, 320),
+    # --v2 (train.py:302-307): concatenated skips, 3x3 classifier, 9-conv belly of 64 planes
+    "robo_unet_v2_640x480_bs32": (dict(noScale=True, planes=8, depth=4, levels=1, bellySize=9, bellyPlanes=64, v2=True, classSize=3),
+                                  32, 480, 640),
 }
 
 
@@ -77,7 +80,7 @@ def pmc_traffic(label):
     return (tot / n if n else None), os.path.basename(files[-1])
 
 
-def cpu_baseline(ctor, H, W, budget_s=20.0):
+def cpu_baseline(ctor, H, W, budget_s=20.0, dice=False):
     """The CPU oracle on this host: same step body, all host threads, bounded sample."""
     from oracle import cpu_reference as O
     threads = os.cpu_count() or 1
@@ -93,7 +96,7 @@ def cpu_baseline(ctor, H, W, budget_s=20.0):
         import robocupvision_amd.model as M
         sd = M.ROBO_UNet(**ctor).state_dict()
         cfg = O.NetConfig(**ctor)
-        st = O.TrainState(sd, cfg)
+        st = O.TrainState(sd, cfg, ce_weight=(1, 2, 6, 3, 2), use_dice=True) if dice else O.TrainState(sd, cfg)
         B = 2 if H * W >= 480 * 640 else 8
         x, t = O.synthetic_batch(B, H, W)
         O.train_step(st, x, t)                     # warm-up
@@ -118,6 +121,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="robo_unet_640x480_bs32", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch size")
+    ap.add_argument("--dice", action="store_true", help="train with DiceLoss (train.py --useDice) instead of the cross entropy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
@@ -151,7 +155,8 @@ def main():
     model = M.ROBO_UNet(**ctor).to(dev)
     x, t = synthetic(B, H, W, seed=1 + rank)
     x, t = x.to(dev), t.to(dev)
-    trainer = Trainer(model, class_weights=[1, 10, 30, 10, 2], lr=1e-3, decay=1e-6, distributed=dist is not None)
+    trainer = Trainer(model, class_weights=[1, 2, 6, 3, 2] if args.dice else [1, 10, 30, 10, 2], lr=1e-3, decay=1e-6,
+                      distributed=dist is not None, use_dice=args.dice)
 
     for _ in range(args.warmup):
         trainer.step(x, t)
@@ -217,7 +222,7 @@ def main():
                     print("%-28s ms %8.4f  %7.2f TF/s %8.1f GB/s" % (r["label"], r["ms"], r["flops"] / max(r["ms"], 1e-9) / 1e9,
                                                                    r["bytes"] / max(r["ms"], 1e-9) / 1e6), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(ctor, H, W)
+        out["cpu_baseline"] = cpu_baseline(ctor, H, W, dice=args.dice)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -78,8 +78,12 @@ enum {
   RCV_OP_CONV1X1     = 18, /* generic 1x1 convolution NHWC -> NHWC/NCHW (LabelProp classifier)   */
   RCV_OP_ADD_SLICE   = 19, /* x[..., 0:Ca] += affine(a)   (LabelProp top skip, model.py:565)     */
   RCV_OP_MATERIALIZE = 20, /* out = load(in)  (a block's normalised output as a plain tensor)    */
-  RCV_OP_BWD_STATS   = 21, /* out = g; partial rows of the BN-backward sums of g against e       */
-  RCV_OP_CONFUSION   = 22  /* counts[n][pred][label] += 1 per pixel (int32, accumulating)            */
+  RCV_OP_BWD_STATS   = 21, /* out = g[.., aux0:aux0+cout] (g has cin channels per pixel, 0 = cout); partial rows of the BN-backward sums */
+  RCV_OP_CONFUSION   = 22, /* counts[n][pred][label] += 1 per pixel (int32, accumulating)            */
+  RCV_OP_DICE_FWD    = 23, /* weighted soft-Dice loss forward (+argmax, +#correct)   model.py:5-43 */
+  RCV_OP_DICE_BWD    = 24, /* d loss / d logits of the Dice loss                                  */
+  RCV_OP_NHWC_TO_NCHW= 25, /* out[n][c][p] = in[n][p][c] + bias[c], c < cout <= cin (3x3 classifier tail) */
+  RCV_OP_NCHW_TO_NHWC= 26  /* out[n][p][c] = c < cin ? in[n][c][p] : 0, cout channels per pixel     */
 };
 
 /* how an operand is produced from memory while it is staged (rcv_op.i[RCV_I_INMODE] etc.) */
@@ -109,6 +113,7 @@ enum {
 #define RCV_F_TRANSPOSED_SRC 32u /* PACK / WGRAD_REDUCE: parameter is [Cin][Cout][3][3] (convT)  */
 #define RCV_F_ARGMAX    64u   /* CE_FWD: also write argmax mask and count correct pixels          */
 #define RCV_F_TRAINING  128u  /* BN_FINALIZE: update running stats                                */
+#define RCV_F_CONCAT    256u  /* COMBINE: out[..,0:C] = relu(t*s+h), out[..,C:2C] = f(r)  (v2 skip concat, model.py:507) */
 #define RCV_F_DBG_NOSTAGE (1u << 20) /* profiling ablation: skip the global->LDS input staging (results are garbage) */
 #define RCV_F_DBG_NOMFMA  (1u << 21) /* profiling ablation: skip the MFMA contraction (results are garbage)          */
 
@@ -223,6 +228,15 @@ int rcv_softmax_ce_argmax_fwd(rcv_handle* h, const float* logits, const int64_t*
 int rcv_softmax_ce_bwd(rcv_handle* h, const float* logits, const int64_t* target,
                        const float* class_weight, const float* loss_out, const float* grad_out,
                        int N, int C, int H, int W, float* dlogits, void* stream);
+
+/* DiceLoss (model.py:5-43, multi-class branch; train.py:315 --useDice) + arg-max / pixel accuracy.  class_weight is
+ * the already rescaled weight vector (model.py:8).  out: float[4 + 16]: [0] = loss, [2] = #correct, [4..] = the
+ * per-class coefficients rcv_dice_bwd consumes.                                                                   */
+int rcv_dice_fwd(rcv_handle* h, const float* logits, const int64_t* target, const float* class_weight /*may be NULL*/,
+                 float eps, int N, int C, int H, int W, float* part, int n_part, float* out,
+                 uint8_t* argmax /*may be NULL*/, void* stream);
+int rcv_dice_bwd(rcv_handle* h, const float* logits, const int64_t* target, const float* fwd_out, const float* grad_out,
+                 int N, int C, int H, int W, float* dlogits, void* stream);
 
 /* train.py:23-27,52-55 (decay * L1 -> gradient decay*sign(p)) + torch.optim.Adam.step            *
  * (train.py:67,357-363) over one flat fp32 buffer; lr is per element group via lr_scale[].      */

@@ -130,6 +130,23 @@ def cross_entropy_2d(logits: Tensor, target: Tensor, weight: Optional[Tensor]) -
     return F.nll_loss(F.log_softmax(logits, dim=1), target, weight, reduction="mean")
 
 
+def dice_weights(weights: Tensor) -> Tensor:
+    """model.py:6-9: class weights rescaled to mean 1."""
+    return weights / weights.sum().item() * weights.shape[0]
+
+
+def dice_loss(logits: Tensor, target: Tensor, weights: Tensor, eps: float = 1e-7) -> Tensor:
+    """model.py:11-43, multi-class branch (nClass > 1; `weights` already rescaled by dice_weights):
+    1 - mean_c( 2 w_c sum(P_c [t==c]) / (sum(P_c) + #[t==c] + eps) ), P = softmax over channels, sums over (B,H,W)."""
+    C = logits.shape[1]
+    one_hot = F.one_hot(target.long(), C).permute(0, 3, 1, 2).to(logits.dtype)
+    probas = F.softmax(logits, dim=1)
+    dims = (0, 2, 3)
+    intersection = torch.sum(probas * one_hot, dims)
+    cardinality = torch.sum(probas + one_hot, dims)
+    return 1 - (2.0 * weights * intersection / (cardinality + eps)).mean()
+
+
 def l1reg(params: Sequence[Tensor]) -> Tensor:
     """train.py:23-27 (sum of |p| over every parameter, BN affine and biases included)."""
     reg = 0
@@ -160,13 +177,14 @@ class TrainState:
     """Parameters as autograd leaves + stock Adam, mirroring train.py:337-366."""
 
     def __init__(self, sd: Dict[str, Tensor], cfg: NetConfig, ce_weight: Sequence[float] = (1, 10, 30, 10, 2),
-                 lr: float = 1e-3, decay: float = 1e-6, transfer: int = 0):
+                 lr: float = 1e-3, decay: float = 1e-6, transfer: int = 0, use_dice: bool = False):
         self.cfg = cfg
         self.sd = {k: v.clone() for k, v in sd.items()}
         self.names = param_names(self.sd)
         for n in self.names:
             self.sd[n].requires_grad_(True)
         self.ce_weight = torch.tensor(list(ce_weight), dtype=torch.float32)
+        self.use_dice = use_dice          # train.py:315 (--useDice); ce_weight then holds the Dice class weights
         self.decay = decay
         groups = param_groups(self.sd, transfer)
         self.opt = torch.optim.Adam(
@@ -181,7 +199,10 @@ def train_step(st: TrainState, imgs: Tensor, targets: Tensor, do_step: bool = Tr
     """train.py:43-74 (no prune indices): zero_grad, fwd, CE + decay*L1, backward, Adam, argmax."""
     st.opt.zero_grad()
     pred = robo_unet_forward(st.sd, imgs, st.cfg, training=True)
-    ce = cross_entropy_2d(pred, targets, st.ce_weight)
+    if st.use_dice:
+        ce = dice_loss(pred, targets, dice_weights(st.ce_weight))
+    else:
+        ce = cross_entropy_2d(pred, targets, st.ce_weight)
     reg = st.decay * l1reg(st.params())
     loss = ce + reg
     loss.backward()

@@ -18,11 +18,11 @@ RCV_P__N = 20
 
 (OP_CONV, OP_TCONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_BWD, OP_COMBINE, OP_CLS_FWD,
  OP_CLS_BWD, OP_CE_FWD, OP_CE_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ADAM_L1, OP_MEMSET, OP_CONV1X1, OP_ADD_SLICE,
- OP_MATERIALIZE, OP_BWD_STATS, OP_CONFUSION) = range(1, 23)
+ OP_MATERIALIZE, OP_BWD_STATS, OP_CONFUSION, OP_DICE_FWD, OP_DICE_BWD, OP_NHWC_TO_NCHW, OP_NCHW_TO_NHWC) = range(1, 27)
 
 LOAD_PLAIN, LOAD_AFFINE, LOAD_GRAD_ENC, LOAD_GRAD_DEC, LOAD_NCHW, LOAD_AFFINE_RELU = range(6)
 STATS_NONE, STATS_FWD, STATS_BWD_ENC, STATS_BWD_DEC = range(4)
-F_BIAS, F_RELU, F_RESID, F_OUT_NCHW, F_FLIP, F_TRANSPOSED_SRC, F_ARGMAX, F_TRAINING = 1, 2, 4, 8, 16, 32, 64, 128
+F_BIAS, F_RELU, F_RESID, F_OUT_NCHW, F_FLIP, F_TRANSPOSED_SRC, F_ARGMAX, F_TRAINING, F_CONCAT = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 
 class RcvOp(C.Structure):
@@ -41,6 +41,7 @@ EXPORTS = [
     "rcv_run_timed", "rcv_op_kernel_label",
     "rcv_conv3x3", "rcv_convT3x3s2", "rcv_wgrad3x3", "rcv_bn_finalize", "rcv_bn_backward", "rcv_maxpool2x2_fwd",
     "rcv_softmax_ce_argmax_fwd", "rcv_softmax_ce_bwd", "rcv_adam_l1_step", "rcv_confusion",
+    "rcv_dice_fwd", "rcv_dice_bwd",
 ]
 
 

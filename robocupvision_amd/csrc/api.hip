@@ -197,6 +197,30 @@ int rcv_softmax_ce_bwd(rcv_handle* h, const float* logits, const int64_t* target
   return rcv_run(h, &op, 1, stream);
 }
 
+int rcv_dice_fwd(rcv_handle* h, const float* logits, const int64_t* target, const float* class_weight, float eps, int N, int C, int H,
+                 int W, float* part, int n_part, float* out, uint8_t* argmax, void* stream) {
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_DICE_FWD;
+  op.flags = argmax ? RCV_F_ARGMAX : 0;
+  op.i[RCV_I_N] = N; op.i[RCV_I_H] = H; op.i[RCV_I_W] = W; op.i[RCV_I_COUT] = C; op.i[RCV_I_NPART] = n_part;
+  op.f[1] = eps;
+  op.p[RCV_P_IN] = (void*)logits; op.p[RCV_P_IN2] = (void*)target; op.p[RCV_P_W] = (void*)class_weight;
+  op.p[RCV_P_PART] = part; op.p[RCV_P_OUT] = out; op.p[RCV_P_X0] = argmax;
+  return rcv_run(h, &op, 1, stream);
+}
+
+int rcv_dice_bwd(rcv_handle* h, const float* logits, const int64_t* target, const float* fwd_out, const float* grad_out, int N, int C,
+                 int H, int W, float* dlogits, void* stream) {
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_DICE_BWD;
+  op.i[RCV_I_N] = N; op.i[RCV_I_H] = H; op.i[RCV_I_W] = W; op.i[RCV_I_COUT] = C;
+  op.p[RCV_P_IN] = (void*)logits; op.p[RCV_P_IN2] = (void*)target;
+  op.p[RCV_P_X0] = (void*)fwd_out; op.p[RCV_P_X1] = (void*)grad_out; op.p[RCV_P_OUT] = dlogits;
+  return rcv_run(h, &op, 1, stream);
+}
+
 int rcv_confusion(rcv_handle* h, const uint8_t* argmax, const int64_t* target, int N, int C, int H, int W, int32_t* counts, void* stream) {
   rcv_op op;
   memset(&op, 0, sizeof(op));

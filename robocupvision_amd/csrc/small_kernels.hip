@@ -164,6 +164,28 @@ __global__ void combine_kernel(const float* __restrict__ t, const float* __restr
   }
 }
 
+// RCV_F_CONCAT: up[.., 0:C] = relu(t*c0+c1), up[.., C:2C] = f(r)   (torch.cat([layer(up), skip], 1), model.py:507)
+__global__ void concat_kernel(const float* __restrict__ t, const float* __restrict__ tc, const float* __restrict__ r,
+                              const float* __restrict__ rc, float* __restrict__ out, size_t n4, int C, int mode2) {
+  const int C4 = C / 4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(e % C4) * 4;
+    const size_t pix = e / C4;
+    const float4 a = sld4(t + e * 4), s = sld4(tc + ch), h = sld4(tc + C + ch);
+    float4 v;
+    v.x = fmaxf(fmaf(a.x, s.x, h.x), 0.f); v.y = fmaxf(fmaf(a.y, s.y, h.y), 0.f);
+    v.z = fmaxf(fmaf(a.z, s.z, h.z), 0.f); v.w = fmaxf(fmaf(a.w, s.w, h.w), 0.f);
+    float4 b = sld4(r + e * 4);
+    if (mode2 != RCV_LOAD_PLAIN) {
+      const float4 s2 = sld4(rc + ch), h2 = sld4(rc + C + ch);
+      b.x = fmaf(b.x, s2.x, h2.x); b.y = fmaf(b.y, s2.y, h2.y); b.z = fmaf(b.z, s2.z, h2.z); b.w = fmaf(b.w, s2.w, h2.w);
+      if (mode2 == RCV_LOAD_AFFINE_RELU) { b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f); }
+    }
+    sst4(out + pix * 2 * C + ch, v);
+    sst4(out + pix * 2 * C + C + ch, b);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // 1x1 classifier (model.py:411): NHWC [.,CIN] -> NCHW logits [N][COUT][H][W]
 // ------------------------------------------------------------------------------------------
@@ -395,6 +417,165 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* _
 }
 
 // ------------------------------------------------------------------------------------------
+// DiceLoss (model.py:5-43, multi-class branch): loss = 1 - mean_c( 2 w_c I_c / (S_c + N_c + eps) ),
+//   I_c = sum_p P[p][c] [t_p == c],  S_c = sum_p P[p][c],  N_c = #[t_p == c],  P = softmax over channels.
+// Forward writes out[0] = loss, out[2] = #pixels whose arg-max equals the target, and the per-class backward
+// coefficients out[4+c] = A_c, out[12+c] = B_c with d loss / d P[p][c] = A_c [t_p == c] + B_c.
+// ------------------------------------------------------------------------------------------
+#define DICE_ROW (3 * CE_MAX_C + 1)
+__global__ void dice_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, int N, int C, int HW,
+                                float* __restrict__ part, uint8_t* __restrict__ argmax) {
+  __shared__ double sh[4][DICE_ROW];
+  double acc[DICE_ROW];
+#pragma unroll
+  for (int j = 0; j < DICE_ROW; ++j) acc[j] = 0.0;
+  const size_t total = (size_t)N * HW;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = p / HW, hw = p % HW;
+    float v[CE_MAX_C];
+    float mx = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c) {
+      if (c < C) {
+        v[c] = logits[(n * C + c) * HW + hw];
+        if (v[c] > mx) { mx = v[c]; am = c; }
+      }
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c) if (c < C) { v[c] = expf(v[c] - mx); se += v[c]; }
+    const float inv = 1.f / se;
+    const int tg = (int)target[p];
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c) {
+      if (c < C) {
+        const double pc = (double)(v[c] * inv);
+        acc[CE_MAX_C + c] += pc;
+        if (c == tg) { acc[c] += pc; acc[2 * CE_MAX_C + c] += 1.0; }
+      }
+    }
+    acc[3 * CE_MAX_C] += (am == tg) ? 1.0 : 0.0;
+    if (argmax) argmax[p] = (uint8_t)am;
+  }
+  const int wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < DICE_ROW; ++j) {
+    const double s = wave_sum_d(acc[j]);
+    if ((threadIdx.x & 63) == 0) sh[wv][j] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < DICE_ROW) {
+    double s = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sh[i][threadIdx.x];
+    part[(size_t)blockIdx.x * DICE_ROW + threadIdx.x] = (float)s;
+  }
+}
+
+__global__ void dice_finalize_kernel(const float* __restrict__ part, int n_part, const float* __restrict__ cw, int C, float eps,
+                                     float* __restrict__ out) {
+  __shared__ double tot[DICE_ROW];
+  __shared__ double sh[4];
+  // one column of the partial rows per pass, fixed order
+  for (int j = 0; j < DICE_ROW; ++j) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) s += (double)part[(size_t)i * DICE_ROW + j];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i]; tot[j] = t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double dice = 0.0;
+    for (int c = 0; c < CE_MAX_C; ++c) {
+      double A = 0.0, B = 0.0;
+      if (c < C) {
+        const double w = cw ? (double)cw[c] : 1.0;
+        const double I = tot[c], K = tot[CE_MAX_C + c] + tot[2 * CE_MAX_C + c] + (double)eps;
+        dice += 2.0 * w * I / K;
+        A = -(2.0 * w / C) / K;
+        B = (2.0 * w / C) * I / (K * K);
+      }
+      out[4 + c] = (float)A;
+      out[4 + CE_MAX_C + c] = (float)B;
+    }
+    out[0] = (float)(1.0 - dice / C);
+    out[1] = 0.f;
+    out[2] = (float)tot[3 * CE_MAX_C];
+    out[3] = 0.f;
+  }
+}
+
+__global__ void dice_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, const float* __restrict__ fwd_out,
+                                const float* __restrict__ grad_out, int N, int C, int HW, float* __restrict__ dlogits) {
+  const float go = grad_out[0];
+  float A[CE_MAX_C], B[CE_MAX_C];
+#pragma unroll
+  for (int c = 0; c < CE_MAX_C; ++c) { A[c] = fwd_out[4 + c]; B[c] = fwd_out[4 + CE_MAX_C + c]; }
+  const size_t total = (size_t)N * HW;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = p / HW, hw = p % HW;
+    float v[CE_MAX_C];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c) if (c < C) { v[c] = logits[(n * C + c) * HW + hw]; mx = fmaxf(mx, v[c]); }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c) if (c < C) { v[c] = expf(v[c] - mx); se += v[c]; }
+    const float inv = 1.f / se;
+    const int tg = (int)target[p];
+    float dot = 0.f;
+    float gq[CE_MAX_C];
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c) {
+      if (c < C) {
+        v[c] *= inv;
+        gq[c] = B[c] + (c == tg ? A[c] : 0.f);
+        dot = fmaf(v[c], gq[c], dot);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CE_MAX_C; ++c)
+      if (c < C) dlogits[(n * C + c) * HW + hw] = go * v[c] * (gq[c] - dot);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Layout changes around the 3x3 classifier of the v2 net (model.py:411 with size=3, model.py:493):
+// the convolution runs NHWC with its 5 output channels padded to 8; the logits the caller sees are NCHW.
+// ------------------------------------------------------------------------------------------
+template <int CP>
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out, int N, int HW,
+                                    int C) {
+  const size_t total = (size_t)N * HW;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = p / HW, hw = p % HW;
+    float v[CP];
+#pragma unroll
+    for (int q = 0; q < CP / 4; ++q) {
+      const float4 u = sld4(x + p * CP + 4 * q);
+      v[4 * q] = u.x; v[4 * q + 1] = u.y; v[4 * q + 2] = u.z; v[4 * q + 3] = u.w;
+    }
+#pragma unroll
+    for (int c = 0; c < CP; ++c) if (c < C) out[(n * C + c) * HW + hw] = v[c] + (bias ? bias[c] : 0.f);
+  }
+}
+
+template <int CP>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int HW, int C) {
+  const size_t total = (size_t)N * HW;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = p / HW, hw = p % HW;
+    float v[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) v[c] = c < C ? x[(n * C + c) * HW + hw] : 0.f;
+#pragma unroll
+    for (int q = 0; q < CP / 4; ++q) sst4(out + p * CP + 4 * q, make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // MaxPool2d(2,2) (model.py:97-100) of y = r*c0+c1, and its backward fused with the skip-gradient
 // add and the BatchNorm-backward reductions of the producer.
 // ------------------------------------------------------------------------------------------
@@ -561,16 +742,21 @@ __global__ void materialize_kernel(const float* __restrict__ x, const float* __r
 // out = g and per-workgroup partial rows (sum g[*m], sum g[*m]*e) -- the BatchNorm-backward sums when the
 // gradient arrives from outside the engine (block-level module calls).  blockDim.x % (C/4) == 0.
 __global__ void bwd_stats_kernel(const float* __restrict__ g, const float* __restrict__ ev, const float* __restrict__ ec,
-                                 float* __restrict__ out, float* __restrict__ part, size_t n4, int C, int stats) {
+                                 float* __restrict__ out, float* __restrict__ part, size_t n4, int C, int stats, int Csrc, int coff) {
   extern __shared__ float4 sh4[];
   const int C4 = C / 4;
   const int q = threadIdx.x % C4;
+  if (stats == RCV_STATS_NONE) {      // plain channel-slice copy (skip half of a concatenated gradient)
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x)
+      sst4(out + e * 4, sld4(g + (e / C4) * Csrc + coff + (e % C4) * 4));
+    return;
+  }
   float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
   if (stats == RCV_STATS_BWD_DEC) { c0 = sld4(ec + 4 * q); c1 = sld4(ec + C + 4 * q); }
   const float4 mu = sld4(ec + 2 * C + 4 * q);
   float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
-    float4 v = sld4(g + e * 4);
+    float4 v = sld4(g + (e / C4) * Csrc + coff + (e % C4) * 4);
     sst4(out + e * 4, v);
     const float4 x = sld4(ev + e * 4);
     if (stats == RCV_STATS_BWD_DEC) {
@@ -618,9 +804,10 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   if (query) {
     static const char* names[] = {"?", "conv", "tconv", "wgrad", "wgrad_reduce", "pack", "bn_finalize", "bn_eval", "bn_bwd", "combine",
                                   "cls_fwd", "cls_bwd", "ce_fwd", "ce_bwd", "pool_fwd", "pool_bwd", "adam_l1", "memset", "conv1x1",
-                                  "add_slice", "materialize", "bwd_stats", "confusion"};
+                                  "add_slice", "materialize", "bwd_stats", "confusion", "dice_fwd", "dice_bwd", "nhwc_to_nchw",
+                                  "nchw_to_nhwc"};
     query->n_part = 0; query->n_split = 0; query->part_bytes = 0;
-    snprintf(query->label, sizeof(query->label), "%s", (op->kind > 0 && op->kind <= 22) ? names[op->kind] : "?");
+    snprintf(query->label, sizeof(query->label), "%s", (op->kind > 0 && op->kind <= 26) ? names[op->kind] : "?");
   }
   switch (op->kind) {
     case RCV_OP_PACK: {
@@ -668,13 +855,15 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       const size_t n4 = (size_t)N * H * W * Cout / 4;
       const int g = stream_grid(h, n4, 256);
       const int m2 = op->i[RCV_I_INMODE2];
+      RCV_CHECK_ARG(m2 == RCV_LOAD_PLAIN || m2 == RCV_LOAD_AFFINE || m2 == RCV_LOAD_AFFINE_RELU, "combine: skip load mode %d unsupported", m2);
       RCV_CHECK_ARG(m2 == RCV_LOAD_PLAIN || op->p[RCV_P_IN2_C], "combine: skip constants missing");
-      if (m2 == RCV_LOAD_PLAIN)
-        hipLaunchKernelGGL(combine_kernel<RCV_LOAD_PLAIN>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN_C], (const float*)op->p[RCV_P_IN2], (const float*)op->p[RCV_P_IN2_C], (float*)op->p[RCV_P_OUT], n4, Cout);
-      else if (m2 == RCV_LOAD_AFFINE)
-        hipLaunchKernelGGL(combine_kernel<RCV_LOAD_AFFINE>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN_C], (const float*)op->p[RCV_P_IN2], (const float*)op->p[RCV_P_IN2_C], (float*)op->p[RCV_P_OUT], n4, Cout);
-      else
-        hipLaunchKernelGGL(combine_kernel<RCV_LOAD_AFFINE_RELU>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN_C], (const float*)op->p[RCV_P_IN2], (const float*)op->p[RCV_P_IN2_C], (float*)op->p[RCV_P_OUT], n4, Cout);
+      const float* t = (const float*)op->p[RCV_P_IN]; const float* tc = (const float*)op->p[RCV_P_IN_C];
+      const float* r = (const float*)op->p[RCV_P_IN2]; const float* rc = (const float*)op->p[RCV_P_IN2_C];
+      float* out = (float*)op->p[RCV_P_OUT];
+      if (op->flags & RCV_F_CONCAT) hipLaunchKernelGGL(concat_kernel, dim3(g), dim3(256), 0, s, t, tc, r, rc, out, n4, Cout, m2);
+      else if (m2 == RCV_LOAD_PLAIN) hipLaunchKernelGGL(combine_kernel<RCV_LOAD_PLAIN>, dim3(g), dim3(256), 0, s, t, tc, r, rc, out, n4, Cout);
+      else if (m2 == RCV_LOAD_AFFINE) hipLaunchKernelGGL(combine_kernel<RCV_LOAD_AFFINE>, dim3(g), dim3(256), 0, s, t, tc, r, rc, out, n4, Cout);
+      else hipLaunchKernelGGL(combine_kernel<RCV_LOAD_AFFINE_RELU>, dim3(g), dim3(256), 0, s, t, tc, r, rc, out, n4, Cout);
       break;
     }
     case RCV_OP_CLS_FWD: {
@@ -823,15 +1012,64 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     case RCV_OP_BWD_STATS: {
       RCV_CHECK_ARG(Cout % 4 == 0 && Cout <= 1024 && 256 % (Cout / 4) == 0, "bwd_stats: C=%d unsupported", Cout);
       const size_t n4 = (size_t)N * H * W * Cout / 4;
-      const int g = reduce_grid(h, n4, 256);
       const int stats = op->i[RCV_I_STATS];
+      const int Csrc = Cin > 0 ? Cin : Cout, coff = op->i[RCV_I_AUX0];
+      RCV_CHECK_ARG(Csrc % 4 == 0 && coff % 4 == 0 && coff >= 0 && coff + Cout <= Csrc, "bwd_stats: slice [%d,%d) of %d channels", coff,
+                    coff + Cout, Csrc);
+      if (stats == RCV_STATS_NONE) {
+        if (query) return RCV_OK;
+        RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_OUT], "bwd_stats: null operand");
+        hipLaunchKernelGGL(bwd_stats_kernel, dim3(stream_grid(h, n4, 256)), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)nullptr,
+                           (const float*)nullptr, (float*)op->p[RCV_P_OUT], (float*)nullptr, n4, Cout, stats, Csrc, coff);
+        break;
+      }
+      const int g = reduce_grid(h, n4, 256);
       if (query) { query->n_part = g; query->part_bytes = (size_t)g * 2 * Cout * sizeof(float); return RCV_OK; }
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_EPI_AUX] && op->p[RCV_P_OUT] && op->p[RCV_P_PART], "bwd_stats: null operand");
       RCV_CHECK_ARG(op->p[RCV_P_EPI_C], "bwd_stats: constants (scale, shift, mean) missing");
       RCV_CHECK_ARG(op->i[RCV_I_NPART] == g, "bwd_stats: workspace rows %d != %d", op->i[RCV_I_NPART], g);
       hipLaunchKernelGGL(bwd_stats_kernel, dim3(g), dim3(256), 2 * 256 * sizeof(float4), s, (const float*)op->p[RCV_P_IN],
                          (const float*)op->p[RCV_P_EPI_AUX], (const float*)op->p[RCV_P_EPI_C], (float*)op->p[RCV_P_OUT],
-                         (float*)op->p[RCV_P_PART], n4, Cout, stats);
+                         (float*)op->p[RCV_P_PART], n4, Cout, stats, Csrc, coff);
+      break;
+    }
+    case RCV_OP_DICE_FWD: {
+      const int HW = H * W;
+      const int g = reduce_grid(h, (size_t)N * HW, 256);
+      if (query) { query->n_part = g; query->part_bytes = (size_t)g * DICE_ROW * sizeof(float); return RCV_OK; }
+      RCV_CHECK_ARG(Cout >= 2 && Cout <= CE_MAX_C, "dice loss: %d classes unsupported (2..%d)", Cout, CE_MAX_C);
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_PART] && op->p[RCV_P_OUT], "dice loss: null operand");
+      RCV_CHECK_ARG(op->i[RCV_I_NPART] == g, "dice loss: workspace rows %d != %d", op->i[RCV_I_NPART], g);
+      hipLaunchKernelGGL(dice_fwd_kernel, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const int64_t*)op->p[RCV_P_IN2], N, Cout,
+                         HW, (float*)op->p[RCV_P_PART], (op->flags & RCV_F_ARGMAX) ? (uint8_t*)op->p[RCV_P_X0] : nullptr);
+      RCV_HIP(hipGetLastError());
+      hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)op->p[RCV_P_PART], g, (const float*)op->p[RCV_P_W],
+                         Cout, op->f[1], (float*)op->p[RCV_P_OUT]);
+      break;
+    }
+    case RCV_OP_DICE_BWD: {
+      if (query) return RCV_OK;
+      RCV_CHECK_ARG(Cout >= 2 && Cout <= CE_MAX_C, "dice loss: %d classes unsupported", Cout);
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_X0] && op->p[RCV_P_X1] && op->p[RCV_P_OUT], "dice loss backward: null operand");
+      hipLaunchKernelGGL(dice_bwd_kernel, dim3(stream_grid(h, (size_t)N * H * W, 256)), dim3(256), 0, s, (const float*)op->p[RCV_P_IN],
+                         (const int64_t*)op->p[RCV_P_IN2], (const float*)op->p[RCV_P_X0], (const float*)op->p[RCV_P_X1], N, Cout, H * W,
+                         (float*)op->p[RCV_P_OUT]);
+      break;
+    }
+    case RCV_OP_NHWC_TO_NCHW: {
+      if (query) return RCV_OK;
+      RCV_CHECK_ARG(Cin == 8 && Cout >= 1 && Cout <= 8, "nhwc_to_nchw: %d -> %d channels unsupported (8 padded channels)", Cin, Cout);
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_OUT], "nhwc_to_nchw: null operand");
+      hipLaunchKernelGGL(nhwc_to_nchw_kernel<8>, dim3(stream_grid(h, (size_t)N * H * W, 256)), dim3(256), 0, s, (const float*)op->p[RCV_P_IN],
+                         (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout);
+      break;
+    }
+    case RCV_OP_NCHW_TO_NHWC: {
+      if (query) return RCV_OK;
+      RCV_CHECK_ARG(Cout == 8 && Cin >= 1 && Cin <= 8, "nchw_to_nhwc: %d -> %d channels unsupported (8 padded channels)", Cin, Cout);
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_OUT], "nchw_to_nhwc: null operand");
+      hipLaunchKernelGGL(nchw_to_nhwc_kernel<8>, dim3(stream_grid(h, (size_t)N * H * W, 256)), dim3(256), 0, s, (const float*)op->p[RCV_P_IN],
+                         (float*)op->p[RCV_P_OUT], N, H * W, Cin);
       break;
     }
     default:

@@ -26,6 +26,7 @@ from . import _lib as L
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+CLS3_PAD = 8                    # class channels of the 3x3 classifier (v2) are padded to this many NHWC channels
 MERGED_TCONV_MAX_COUT = 16      # transposed convs with at most this many output channels use the merged-parity kernel
 
 
@@ -314,12 +315,14 @@ class Engine:
                     if (skip.C, skip.H, skip.W) != (Cout, Ho, Wo):
                         raise L.RcvError("up node %d: skip tensor %s does not match output %s" %
                                          (node.idx, (skip.C, skip.H, skip.W), (Cout, Ho, Wo)))
-                    up = self._alloc(plan, N, Ho, Wo, Cout)
-                    cop = L.make_op(L.OP_COMBINE, 0, n=N, h=Ho, w=Wo, cout=Cout, inmode2=skip.load_mode, p_in=t.data_ptr(),
-                                    p_in_c=node.t["consts"].data_ptr(), p_in2_c=_ptr(skip.consts), p_out=up.data_ptr())
+                    concat = bool(d.get("concat"))      # v2: torch.cat([layer(up), skip], 1) instead of the add (model.py:507)
+                    Cup = 2 * Cout if concat else Cout
+                    up = self._alloc(plan, N, Ho, Wo, Cup)
+                    cop = L.make_op(L.OP_COMBINE, L.F_CONCAT if concat else 0, n=N, h=Ho, w=Wo, cout=Cout, inmode2=skip.load_mode,
+                                    p_in=t.data_ptr(), p_in_c=node.t["consts"].data_ptr(), p_in2_c=_ptr(skip.consts), p_out=up.data_ptr())
                     cop.p[L.RCV_P_IN2] = bind_in(fwd, skip, L.RCV_P_IN2) or None
                     fwd.append(cop)
-                    node.out = Value("plain", up, Cout, Ho, Wo, None, node)
+                    node.out = Value("plain", up, Cup, Ho, Wo, None, node)
                 else:
                     node.out = Value("affine_relu", t, Cout, Ho, Wo, node.t["consts"], node)
             elif node.op == "cls":
@@ -328,13 +331,27 @@ class Engine:
                 Cout, Cin = w.shape[0], w.shape[1]
                 if src.kind != "plain":
                     raise L.RcvError("classifier input must be a materialised tensor")
-                if w.shape[2] != 1 or w.shape[3] != 1:
-                    raise L.RcvError("only the 1x1 classifier (classSize=1) is built; got %dx%d" % (w.shape[2], w.shape[3]))
+                if Cin != src.C:
+                    raise L.RcvError("classifier: input has %d channels, weight expects %d" % (src.C, Cin))
                 logits = self._alloc(plan, N, Cout, src.H, src.W)
-                op = L.make_op(L.OP_CLS_FWD, 0, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, p_w=w.data_ptr(), p_bias=_ptr(b),
-                               p_out=logits.data_ptr())
-                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
-                fwd.append(op)
+                if tuple(w.shape[2:]) == (1, 1):
+                    op = L.make_op(L.OP_CLS_FWD, 0, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, p_w=w.data_ptr(), p_bias=_ptr(b),
+                                   p_out=logits.data_ptr())
+                    op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
+                    fwd.append(op)
+                elif tuple(w.shape[2:]) == (3, 3) and Cout <= CLS3_PAD:
+                    # v2 (classSize=3): the MFMA conv with the class channels padded to 8, NHWC; then bias + NHWC -> NCHW
+                    node.t["wp"] = add_pack(w, Cout, Cin, True, False)
+                    node.t["z"] = self._alloc(plan, N, src.H, src.W, CLS3_PAD)
+                    op = L.make_op(L.OP_CONV, 0, n=N, h=src.H, w=src.W, cin=Cin, cout=CLS3_PAD, ho=src.H, wo=src.W, stride=1, dil=1,
+                                   inmode=src.load_mode, p_w=node.t["wp"].data_ptr(), p_out=node.t["z"].data_ptr())
+                    op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
+                    fwd.append(op)
+                    fwd.append(L.make_op(L.OP_NHWC_TO_NCHW, 0, n=N, h=src.H, w=src.W, cin=CLS3_PAD, cout=Cout, p_in=node.t["z"].data_ptr(),
+                                         p_bias=_ptr(b), p_out=logits.data_ptr()))
+                else:
+                    raise L.RcvError("classifier kernels %s with %d classes are not built (1x1, or 3x3 with <= %d classes)"
+                                     % (tuple(w.shape[2:]), Cout, CLS3_PAD))
                 node.out = Value("plain", logits, Cout, src.H, src.W, None, node)
                 plan.logits = logits
             elif node.op == "add_slice":
@@ -389,14 +406,14 @@ class Engine:
                     writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_ENC
                     writer_op.p[L.RCV_P_EPI_AUX] = v.buf.data_ptr()
                     writer_op.p[L.RCV_P_EPI_C] = prod.t["consts"].data_ptr()     # row 2 = batch mean
-                elif prod.op == "up":
+                elif prod.op == "up" and not prod.d.get("concat"):
                     writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_DEC
                     writer_op.p[L.RCV_P_EPI_AUX] = prod.t["t"].data_ptr()
                     writer_op.p[L.RCV_P_EPI_C] = prod.t["consts"].data_ptr()
                 else:
                     writer_op.i[L.RCV_I_STATS] = L.STATS_NONE
                 self._workspace(plan, writer_op)
-                if prod is not None and prod.op in ("conv", "up"):
+                if writer_op.i[L.RCV_I_STATS] != L.STATS_NONE:
                     prod.t["bwd_part"] = (writer_op.p[L.RCV_P_PART], writer_op.i[L.RCV_I_NPART])
 
             def emit_bn_backward(node: _Node, bn, Cc: int, Ho: int, Wo: int):
@@ -423,6 +440,27 @@ class Engine:
                     src = ref(d["src"])
                     w, b = d["weight"], d.get("bias")
                     Cout, Cin = w.shape[0], w.shape[1]
+                    if "z" in node.t:      # 3x3 classifier: NCHW dlogits -> padded NHWC, then the ordinary filter / data gradients
+                        if src.input_index is not None:
+                            raise L.RcvError("the 3x3 classifier cannot read a graph input directly")
+                        g8 = self._alloc(plan, N, src.H, src.W, CLS3_PAD)
+                        plan.dlogits_slots.append((len(bwd), L.RCV_P_IN))
+                        bwd.append(L.make_op(L.OP_NCHW_TO_NHWC, 0, n=N, h=src.H, w=src.W, cin=Cout, cout=CLS3_PAD, p_out=g8.data_ptr()))
+                        wop = L.make_op(L.OP_WGRAD, (L.F_BIAS if b is not None else 0), n=N, h=src.H, w=src.W, cin=Cin, ho=src.H, wo=src.W,
+                                        cout=CLS3_PAD, stride=1, dil=1, inmode=src.load_mode, inmode2=L.LOAD_PLAIN,
+                                        p_in=src.buf.data_ptr(), p_in_c=_ptr(src.consts), p_in2=g8.data_ptr())
+                        self._workspace(plan, wop)
+                        bwd.append(wop)
+                        bwd.append(L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cin, cout=Cout, nsplit=wop.i[L.RCV_I_NSPLIT],
+                                             p_part=wop.p[L.RCV_P_PART], p_out=fl.grad_ptr(w),
+                                             p_bias=(fl.grad_ptr(b) if b is not None else 0)))
+                        if src.needs_grad:
+                            node.t["wd"] = add_pack(w, Cout, Cin, False, True)
+                            dop = L.make_op(L.OP_CONV, 0, n=N, h=src.H, w=src.W, cin=CLS3_PAD, cout=Cin, ho=src.H, wo=src.W, stride=1, dil=1,
+                                            inmode=L.LOAD_PLAIN, p_in=g8.data_ptr(), p_w=node.t["wd"].data_ptr())
+                            grad_target(src, dop, src.H, src.W)
+                            bwd.append(dop)
+                        continue
                     op = L.make_op(L.OP_CLS_BWD, 0, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, p_in=src.buf.data_ptr() if src.buf is not None else 0,
                                    p_w=w.data_ptr(), p_x1=fl.grad_ptr(w), p_x2=(fl.grad_ptr(b) if b is not None else 0))
                     if src.input_index is not None:
@@ -445,12 +483,27 @@ class Engine:
                     Cin, Cout = w.shape[0], w.shape[1]
                     if out.grad is None:
                         raise L.RcvError("up node %d has no consumer that produces its gradient" % node.idx)
-                    if d.get("skip") is not None:
+                    gout = out.grad
+                    if d.get("skip") is not None and d.get("concat"):
+                        # gradient of the concatenation: channels [0,C) belong to this block (copied out together with its
+                        # BatchNorm-backward sums), channels [C,2C) to the skip tensor
+                        gout = self._alloc(plan, N, out.H, out.W, Cout)
+                        sop = L.make_op(L.OP_BWD_STATS, 0, n=N, h=out.H, w=out.W, cin=2 * Cout, cout=Cout, aux0=0, stats=L.STATS_BWD_DEC,
+                                        p_in=out.grad.data_ptr(), p_epi_aux=node.t["t"].data_ptr(), p_epi_c=node.t["consts"].data_ptr(),
+                                        p_out=gout.data_ptr())
+                        self._workspace(plan, sop)
+                        node.t["bwd_part"] = (sop.p[L.RCV_P_PART], sop.i[L.RCV_I_NPART])
+                        bwd.append(sop)
+                        gskip = self._alloc(plan, N, out.H, out.W, Cout)
+                        bwd.append(L.make_op(L.OP_BWD_STATS, 0, n=N, h=out.H, w=out.W, cin=2 * Cout, cout=Cout, aux0=Cout, stats=L.STATS_NONE,
+                                             p_in=out.grad.data_ptr(), p_out=gskip.data_ptr()))
+                        ref(d["skip"]).skip_grad = gskip
+                    elif d.get("skip") is not None:
                         ref(d["skip"]).skip_grad = out.grad        # d up / d skip = identity
                     emit_bn_backward(node, bn, Cout, out.H, out.W)
                     # filter gradient: G = dt (2x plane), P = layer input
                     wop = L.make_op(L.OP_WGRAD, 0, n=N, h=out.H, w=out.W, cin=Cout, ho=src.H, wo=src.W, cout=Cin, stride=2, dil=1,
-                                    inmode=L.LOAD_GRAD_DEC, inmode2=src.load_mode, p_in=out.grad.data_ptr(),
+                                    inmode=L.LOAD_GRAD_DEC, inmode2=src.load_mode, p_in=gout.data_ptr(),
                                     p_in_aux=node.t["t"].data_ptr(), p_in_c=node.t["bconsts"].data_ptr(),
                                     p_in2_c=_ptr(src.consts))
                     wop.p[L.RCV_P_IN2] = (src.buf.data_ptr() if src.buf is not None else None)
@@ -465,7 +518,7 @@ class Engine:
                     if src.needs_grad:
                         node.t["wd"] = add_pack(w, Cin, Cout, True, False)
                         dop = L.make_op(L.OP_CONV, 0, n=N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=2, dil=1,
-                                        inmode=L.LOAD_GRAD_DEC, p_in=out.grad.data_ptr(), p_in_aux=node.t["t"].data_ptr(),
+                                        inmode=L.LOAD_GRAD_DEC, p_in=gout.data_ptr(), p_in_aux=node.t["t"].data_ptr(),
                                         p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
                         grad_target(src, dop, src.H, src.W)
                         bwd.append(dop)

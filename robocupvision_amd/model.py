@@ -175,8 +175,9 @@ class upSampleTransposeConv(nn.Module, _BlockMixin):
         self.conv = nn.ConvTranspose2d(inplanes, planes, kernel_size=3, padding=1, stride=2, output_padding=1, bias=True)
         self.bn = nn.BatchNorm2d(planes)
 
-    def _node(self, src, skip):
-        return {"op": "up", "src": src, "skip": skip, "weight": self.conv.weight, "bias": self.conv.bias, "bn": self.bn}
+    def _node(self, src, skip, concat=False):
+        return {"op": "up", "src": src, "skip": skip, "concat": concat, "weight": self.conv.weight, "bias": self.conv.bias,
+                "bn": self.bn}
 
     def _block_graph(self):
         return {"inputs": [{"layout": "nhwc", "requires_grad": True}],
@@ -225,13 +226,15 @@ class LevelDown(nn.Module):
 
 
 class UltClassifier(nn.Module):
-    """1x1 classifier (model.py:403-414); the pooled/dropout variant belongs to the patch
-    classification scripts and is out of scope."""
+    """1x1 (or, for the v2 net, 3x3) classifier (model.py:403-414); the pooled/dropout variant belongs to the
+    patch classification scripts and is out of scope."""
 
     def __init__(self, inplanes, nClass, pool, dropout=0.5, size=1):
         super().__init__()
         if pool:
             raise NotImplementedError("UltClassifier(pool=True) (patch classification) is outside the segmentation hot path")
+        if size not in (1, 3):
+            raise NotImplementedError("classifier kernel sizes 1 and 3 are built (got %d)" % size)
         self.layers = nn.Sequential()
         self.layers.add_module("Class", nn.Conv2d(inplanes, nClass, size, padding=size // 2))
 
@@ -250,8 +253,6 @@ class ROBO_UNet(nn.Module):
     def __init__(self, noScale=False, planes=8, nClass=5, depth=4, levels=2, bellySize=5, bellyPlanes=128, pool=False, v2=False,
                  classSize=1):
         super().__init__()
-        if v2:
-            raise NotImplementedError("the v2 variant (concatenated skips, 3x3 classifier) is a later row of the scope table")
         self.numClass = nClass
         self.planes = planes
         self.v2 = v2
@@ -274,9 +275,12 @@ class ROBO_UNet(nn.Module):
         self.upPart = nn.ModuleList()
         for i in range(depth - 1):
             nCh = planes * pow(2, depth - 1 - i)
-            self.upPart.add_module("Up%d" % i, upSampleTransposeConv(nCh, nCh // 2))
+            oCh = nCh // 2
+            if i > 0 and v2:      # v2: the previous level's output is concatenated with its skip tensor (model.py:487-488,507)
+                nCh *= 2
+            self.upPart.add_module("Up%d" % i, upSampleTransposeConv(nCh, oCh))
 
-        self.segmenter = UltClassifier(planes, nClass, False, size=classSize)
+        self.segmenter = UltClassifier(planes * 2 if v2 else planes, nClass, False, size=classSize)
 
     # graph of model.py:495-511
     def _graph(self):
@@ -288,7 +292,7 @@ class ROBO_UNet(nn.Module):
             downs[-1] = level._nodes(nodes, downs[-1])
         up = downs[-1]
         for i, layer in enumerate(self.upPart):
-            nodes.append(layer._node(up, downs[-(i + 2)]))
+            nodes.append(layer._node(up, downs[-(i + 2)], concat=self.v2))
             up = ("node", len(nodes) - 1)
         nodes.append(self.segmenter._node(up))
         return {"inputs": [{"layout": "nchw"}], "nodes": nodes}
@@ -387,6 +391,68 @@ class CrossEntropyLoss2d(nn.Module):
             w = w.to(inputs.device)
             self.weight = w
         return _CEFunction.apply(inputs, targets, w, self)
+
+
+# ------------------------------------------------------------------------------------------
+# DiceLoss (model.py:5-43; train.py:315 --useDice) + the same fused arg-max / accuracy
+# ------------------------------------------------------------------------------------------
+class _DiceFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, weight, eps, module):
+        if logits.device.type != "cuda":
+            raise L.RcvError("DiceLoss runs on the HIP device only (got %s)" % logits.device)
+        h = L.handle(logits.device.index if logits.device.index is not None else torch.cuda.current_device())
+        logits_c = logits.detach().to(torch.float32).contiguous()
+        N, Cc, H, W = logits_c.shape
+        targets_c = targets.detach().to(torch.int64).reshape(N, H, W).contiguous()     # [B,H,W] or [B,1,H,W] (model.py:36)
+        out = torch.empty(4 + 16, dtype=torch.float32, device=logits.device)
+        argmax = torch.empty(N, H, W, dtype=torch.uint8, device=logits.device)
+        op = L.make_op(L.OP_DICE_FWD, L.F_ARGMAX, n=N, h=H, w=W, cout=Cc, f1=eps, p_in=logits_c.data_ptr(), p_in2=targets_c.data_ptr(),
+                       p_w=weight.data_ptr(), p_out=out.data_ptr(), p_x0=argmax.data_ptr())
+        nbytes = L.op_workspace(h, op)
+        part = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=logits.device)
+        op.p[L.RCV_P_PART] = part.data_ptr()
+        L.OpList([op]).run(h, torch.cuda.current_stream(logits.device).cuda_stream)
+        ctx.save_for_backward(logits_c, targets_c, out)
+        ctx.handle = h
+        module.last_argmax = argmax
+        module.last_stats = out          # [loss, -, #correct, -, backward coefficients...]
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        logits, targets, out = ctx.saved_tensors
+        N, Cc, H, W = logits.shape
+        go = grad_out.detach().to(torch.float32).reshape(1).contiguous()
+        dl = torch.empty_like(logits)
+        op = L.make_op(L.OP_DICE_BWD, 0, n=N, h=H, w=W, cout=Cc, p_in=logits.data_ptr(), p_in2=targets.data_ptr(),
+                       p_x0=out.data_ptr(), p_x1=go.data_ptr(), p_out=dl.data_ptr())
+        L.OpList([op]).run(ctx.handle, torch.cuda.current_stream(logits.device).cuda_stream)
+        return dl, None, None, None, None
+
+
+class DiceLoss(nn.Module):
+    """1 - mean_c(2 w_c I_c / (S_c + N_c + eps)) over softmax probabilities (model.py:5-43, multi-class branch); the
+    class weights are rescaled to mean 1 exactly as model.py:8.  ``last_argmax`` / ``last_stats[2]`` as CrossEntropyLoss2d."""
+
+    def __init__(self, weights, eps=1e-7):
+        super().__init__()
+        weights = torch.as_tensor(weights, dtype=torch.float32)
+        self.register_buffer("weights", (weights / weights.sum().item() * weights.shape[0]).clone())
+        self.eps = eps
+        self.last_argmax: Optional[torch.Tensor] = None
+        self.last_stats: Optional[torch.Tensor] = None
+
+    def forward(self, logits, true):
+        if logits.shape[1] == 1:
+            raise NotImplementedError("the single-class (sigmoid) branch of DiceLoss (model.py:25-33) is not built")
+        if logits.shape[1] != self.weights.shape[0]:
+            raise ValueError("DiceLoss has %d class weights but the logits have %d channels" % (self.weights.shape[0], logits.shape[1]))
+        w = self.weights
+        if w.device != logits.device:
+            w = w.to(logits.device)
+            self.weights = w
+        return _DiceFunction.apply(logits, true, w, float(self.eps), self)
 
 
 # ------------------------------------------------------------------------------------------
@@ -493,6 +559,3 @@ class PB_FCN(_OutOfScope):
 class PB_FCN_2(_OutOfScope):
     _what = "PB_FCN_2"
 
-
-class DiceLoss(_OutOfScope):
-    _what = "DiceLoss (--useDice)"

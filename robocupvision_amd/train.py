@@ -21,20 +21,26 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib as L
-from .model import CrossEntropyLoss2d
+from .model import CrossEntropyLoss2d, DiceLoss
 from .optim import AdamL1
 
 
 class Trainer:
     def __init__(self, model, class_weights: Optional[Sequence[float]] = (1, 10, 30, 10, 2), lr: float = 1e-3,
-                 decay: float = 1e-6, transfer: int = 0, distributed: bool = False, overlap: bool = True):
+                 decay: float = 1e-6, transfer: int = 0, distributed: bool = False, overlap: bool = True,
+                 use_dice: bool = False):
         self.model = model
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise L.RcvError("Trainer needs the model on the HIP device (model.cuda())")
         self.device = dev
         w = None if class_weights is None else torch.tensor(list(class_weights), dtype=torch.float32, device=dev)
-        self.criterion = CrossEntropyLoss2d(w).to(dev)
+        if use_dice:       # train.py:315 (--useDice); class_weights are then the Dice weights of train.py:309
+            if w is None:
+                raise ValueError("DiceLoss needs class weights")
+            self.criterion = DiceLoss(w).to(dev)
+        else:
+            self.criterion = CrossEntropyLoss2d(w).to(dev)
         self.optimizer = AdamL1(model, lr=lr, decay=decay, transfer=transfer)
         self.metrics = torch.zeros(4, dtype=torch.float64, device=dev)     # loss, reg, correct, steps
         self.distributed = distributed

@@ -42,6 +42,26 @@ def net_meta():
         return json.load(f)
 
 
+@pytest.fixture(scope="session")
+def dv_kats():
+    """Dice-loss known answers and whole steps of the v2 net / --useDice (make_golden.py dice_v2)."""
+    return np.load(os.path.join(GOLDEN, "dice_v2.npz"))
+
+
+@pytest.fixture(scope="session")
+def dv_meta():
+    with open(os.path.join(GOLDEN, "dice_v2.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden(net_kats, net_meta, dv_kats, dv_meta):
+    """tag -> (arrays, meta) across both whole-net fixture files."""
+    def lookup(tag):
+        return (net_kats, net_meta[tag]) if tag in net_meta else (dv_kats, dv_meta[tag])
+    return lookup
+
+
 def sd_hash(sd):
     import hashlib
     h = hashlib.sha256()

@@ -126,7 +126,7 @@ def grad_summary(model):
     return rows
 
 
-def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta):
+def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta, dice=False):
     """The train.py:43-74 step on the reference, seeds as SURVEY.md 8(c)."""
     torch.manual_seed(12345678)
     model = ref.ROBO_UNet(**ctor_kwargs)
@@ -134,7 +134,10 @@ def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 3, H, W, generator=g)
     t = torch.randint(0, 5, (B, H, W), generator=g)
-    crit = ref.CrossEntropyLoss2d(torch.tensor([1, 10, 30, 10, 2], dtype=torch.float32))
+    if dice:        # train.py:309,315 (--useDice)
+        crit = ref.DiceLoss(torch.tensor([1, 2, 6, 3, 2], dtype=torch.float32))
+    else:
+        crit = ref.CrossEntropyLoss2d(torch.tensor([1, 10, 30, 10, 2], dtype=torch.float32))
     decay, lr, transfer = 1e-6, 1e-3, 0
     opt = torch.optim.Adam([
         {'params': model.downPart[0:transfer].parameters(), 'lr': lr * 10},
@@ -163,7 +166,7 @@ def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta):
     with torch.no_grad():
         pred_eval = model(x)
     m = {
-        "ctor": ctor_kwargs, "B": B, "H": H, "W": W, "threads": torch.get_num_threads(),
+        "ctor": ctor_kwargs, "dice": bool(dice), "B": B, "H": H, "W": W, "threads": torch.get_num_threads(),
         "torch": torch.__version__, "sd_hash_init": sd_hash(sd0), "sd_hash_after_step": sd_hash(sd1),
         "n_params": int(sum(p.numel() for p in model.parameters())),
         "sum_p": float(sum(v.double().sum() for k, v in sd0.items() if v.dtype.is_floating_point and "running" not in k)),
@@ -184,7 +187,10 @@ def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta):
     # the fp32 reference itself is off by up to ~2e-3 relative there, so parity tests judge against these.
     torch.manual_seed(12345678)
     model64 = ref.ROBO_UNet(**ctor_kwargs).double()
-    crit64 = ref.CrossEntropyLoss2d(torch.tensor([1, 10, 30, 10, 2], dtype=torch.float64))
+    if dice:
+        crit64 = ref.DiceLoss(torch.tensor([1, 2, 6, 3, 2], dtype=torch.float64))
+    else:
+        crit64 = ref.CrossEntropyLoss2d(torch.tensor([1, 10, 30, 10, 2], dtype=torch.float64))
     model64.train()
     pred64 = model64(x.double())
     ce64 = crit64(pred64, t)
@@ -238,6 +244,40 @@ def whole_net(ref, big=True):
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
+def dice_v2(ref, big=True):
+    """DiceLoss (model.py:5-43) known answers, and whole steps of the v2 net (concat skips, 3x3
+    classifier, bellySize 9; train.py:302-307) and of the default net trained with --useDice."""
+    out, meta = {}, {}
+    for name, C, B, H, W, wts, seed in (("dice5", 5, 2, 24, 32, [1, 2, 6, 3, 2], 3), ("dice3", 3, 1, 16, 48, [1, 6, 3], 4),
+                                        ("dice5_sharp", 5, 2, 24, 32, [1, 2, 6, 3, 2], 5)):
+        g = torch.Generator().manual_seed(seed)
+        x = (torch.randn(B, C, H, W, generator=g) * (8.0 if name.endswith("sharp") else 1.5)).requires_grad_(True)
+        t = torch.randint(0, C, (B, H, W), generator=g)
+        w = torch.tensor(wts, dtype=torch.float32)
+        loss = ref.DiceLoss(w)(x, t)
+        loss.backward()
+        x64 = x.detach().double().requires_grad_(True)
+        loss64 = ref.DiceLoss(w.double())(x64, t)
+        loss64.backward()
+        out[name + "/logits"] = npy(x); out[name + "/target"] = npy(t).astype(np.int64); out[name + "/weights"] = npy(w)
+        out[name + "/loss"] = npy(loss); out[name + "/dlogits"] = npy(x.grad)
+        out[name + "/loss64"] = npy(loss64); out[name + "/dlogits64"] = npy(x64.grad)
+        print(name, float(loss), float(loss64))
+    V2_S = dict(noScale=False, planes=8, depth=4, levels=1, bellySize=9, bellyPlanes=64, v2=True, classSize=3)
+    V2_L = dict(noScale=True, planes=8, depth=4, levels=1, bellySize=9, bellyPlanes=64, v2=True, classSize=3)
+    ROBO_S = dict(noScale=False, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128)
+    run_step(ref, V2_S, 2, 48, 64, True, "v2_s_2x48x64", out, meta)
+    run_step(ref, V2_L, 1, 48, 64, True, "v2_l_1x48x64", out, meta)
+    run_step(ref, ROBO_S, 2, 48, 64, True, "robo_s_2x48x64_dice", out, meta, dice=True)
+    run_step(ref, V2_S, 2, 48, 64, True, "v2_s_2x48x64_dice", out, meta, dice=True)
+    if big:
+        run_step(ref, V2_L, 2, 480, 640, False, "v2_l_2x480x640", out, meta)
+        run_step(ref, ROBO_S, 4, 120, 160, False, "robo_s_4x120x160_dice", out, meta, dice=True)
+    np.savez_compressed(os.path.join(HERE, "dice_v2.npz"), **out)
+    with open(os.path.join(HERE, "dice_v2.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def labelprop(ref):
     """LabelProp (config 5).  The class cannot be constructed at HEAD (8 args passed to a
     7-arg ConvPoolSimple.__init__), so the generator wraps the constructor to drop the extra
@@ -281,10 +321,12 @@ if __name__ == "__main__":
     torch.set_num_threads(THREADS)
     sys.path.insert(0, REF)
     import model as ref          # the reference, imported (never copied)
-    which = sys.argv[1:] or ["layers", "net", "lp"]
+    which = sys.argv[1:] or ["layers", "net", "lp", "dice_v2"]
     if "layers" in which:
         layer_kats(ref)
     if "net" in which:
         whole_net(ref)
     if "lp" in which:
         labelprop(ref)
+    if "dice_v2" in which:
+        dice_v2(ref)

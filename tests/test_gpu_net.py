@@ -24,9 +24,15 @@ def build(ctor):
     return M.ROBO_UNet(**ctor)
 
 
-def hip_step(model, x, t, decay=1e-6, lr=1e-3, do_step=True):
+DICE_W = [1, 2, 6, 3, 2]        # train.py:309
+
+
+def hip_step(model, x, t, decay=1e-6, lr=1e-3, do_step=True, dice=False):
     """train.py:43-74 with the package's modules (stock Adam: the caller-side part of the step)."""
-    crit = M.CrossEntropyLoss2d(torch.tensor(CE_W, dtype=torch.float32)).to(DEV)
+    if dice:
+        crit = M.DiceLoss(torch.tensor(DICE_W, dtype=torch.float32)).to(DEV)
+    else:
+        crit = M.CrossEntropyLoss2d(torch.tensor(CE_W, dtype=torch.float32)).to(DEV)
     opt = torch.optim.Adam([{"params": model.downPart[0:0].parameters(), "lr": lr * 10},
                             {"params": model.downPart[0:].parameters()}, {"params": model.PB.parameters()},
                             {"params": model.upPart.parameters()}, {"params": model.segmenter.parameters()}], lr=lr)
@@ -62,14 +68,17 @@ def check_mask(pc, golden_mask, near_tie_idx, what):
 SMALL = ["robo_s_2x48x64", "robo_l_1x48x64", "unet_s_2x48x64", "unet_l_1x32x48"]
 
 
-@pytest.mark.parametrize("tag", SMALL)
-def test_step_vs_golden_small(net_kats, net_meta, tag):
-    m = net_meta[tag]
+SMALL_F2 = ["v2_s_2x48x64", "v2_l_1x48x64", "robo_s_2x48x64_dice", "v2_s_2x48x64_dice"]      # v2 net, --useDice
+
+
+@pytest.mark.parametrize("tag", SMALL + SMALL_F2)
+def test_step_vs_golden_small(golden, tag):
+    net_kats, m = golden(tag)
     model = build(m["ctor"])
     assert sd_hash(model.state_dict()) == m["sd_hash_init"]
     model = model.to(DEV)
     x, t = _t(net_kats[tag + "/x"]).to(DEV), _t(net_kats[tag + "/t"]).to(DEV)
-    res = hip_step(model, x, t)
+    res = hip_step(model, x, t, dice=m.get("dice", False))
     close(res["pred"], _t(net_kats[tag + "/logits"]), tag + " logits")
     assert abs(res["ce"] - m["ce"]) <= 1e-3 * abs(m["ce"]), (res["ce"], m["ce"])
     assert abs(res["reg"] - m["reg"]) <= 1e-5 * abs(m["reg"])
@@ -108,15 +117,16 @@ def test_step_vs_golden_small(net_kats, net_meta, tag):
     close(pe, _t(net_kats[tag + "/eval_logits"]), tag + " eval logits", rtol=1e-3)
 
 
-@pytest.mark.parametrize("tag", ["robo_s_4x120x160", "robo_l_2x480x640", "unet_l_2x480x640"])
-def test_step_vs_golden_big(net_kats, net_meta, tag):
+@pytest.mark.parametrize("tag", ["robo_s_4x120x160", "robo_l_2x480x640", "unet_l_2x480x640", "v2_l_2x480x640",
+                                 "robo_s_4x120x160_dice"])
+def test_step_vs_golden_big(golden, tag):
     """BASELINE shapes: checksums + the full arg-max mask of the reference."""
-    m = net_meta[tag]
+    net_kats, m = golden(tag)
     model = build(m["ctor"])
     assert sd_hash(model.state_dict()) == m["sd_hash_init"]
     model = model.to(DEV)
     x, t = O.synthetic_batch(m["B"], m["H"], m["W"])
-    res = hip_step(model, x.to(DEV), t.to(DEV))
+    res = hip_step(model, x.to(DEV), t.to(DEV), dice=m.get("dice", False))
     assert abs(res["ce"] - m["ce"]) <= 1e-3 * abs(m["ce"]), (res["ce"], m["ce"])
     ls, las = float(res["pred"].double().sum()), float(res["pred"].double().abs().sum())
     assert abs(las - m["logits_abs_sum"]) <= 1e-3 * m["logits_abs_sum"]
@@ -136,6 +146,24 @@ def test_step_vs_golden_big(net_kats, net_meta, tag):
         # terms: 1e-2 there (the fp32 reference moves by ~1e-3 on them), 1e-3 for the filters
         tol = 1e-2 if (k.endswith("bn.weight") or k.endswith("bn.bias") or k.endswith("conv.bias")) else 1e-3
         assert abs(got - n32) <= tol * n32 + 1e-7 or abs(got - n64) <= tol * n64 + 1e-7, (k, got, n32, n64)
+
+
+@pytest.mark.parametrize("name", ["dice5", "dice3", "dice5_sharp"])
+def test_dice_loss_vs_golden(dv_kats, name):
+    """DiceLoss (model.py:5-43) forward / backward kernels against the reference's own values (fp32 and fp64)."""
+    lg = _t(dv_kats[name + "/logits"]).to(DEV).requires_grad_(True)
+    t = _t(dv_kats[name + "/target"]).to(DEV)
+    crit = M.DiceLoss(_t(dv_kats[name + "/weights"])).to(DEV)
+    loss = crit(lg, t)
+    ref, ref64 = float(dv_kats[name + "/loss"]), float(dv_kats[name + "/loss64"])
+    assert abs(float(loss) - ref) <= 1e-5 * abs(ref) or abs(float(loss) - ref64) <= 1e-6 * abs(ref64), (float(loss), ref, ref64)
+    loss.backward()
+    close(lg.grad, _t(dv_kats[name + "/dlogits64"]).float(), name + " dlogits vs fp64 reference", rtol=1e-4)
+    close(lg.grad, _t(dv_kats[name + "/dlogits"]), name + " dlogits", rtol=1e-3)
+    assert torch.equal(crit.last_argmax.long(), torch.max(lg.detach(), 1)[1])
+    assert int(crit.last_stats[2]) == int((torch.max(lg.detach(), 1)[1] == t).sum())
+    # [B,1,H,W] targets (the docstring form, model.py:17) give the same loss
+    assert float(crit(lg.detach(), t.unsqueeze(1))) == float(loss)
 
 
 def test_step_vs_oracle_on_box():
@@ -185,13 +213,16 @@ def test_grad_accumulation_semantics():
             close(p.grad, 2 * g1[k], "accumulated " + k, rtol=1e-4)
 
 
-@pytest.mark.parametrize("tag", ["robo_s_2x48x64", "unet_s_2x48x64"])
-def test_trainer_fused_step_vs_golden(net_kats, net_meta, tag):
+@pytest.mark.parametrize("tag", ["robo_s_2x48x64", "unet_s_2x48x64", "v2_s_2x48x64", "v2_s_2x48x64_dice"])
+def test_trainer_fused_step_vs_golden(golden, tag):
     """Trainer = fused Adam+L1 kernel over the flat buffers; must land on the reference's post-step parameters."""
     from robocupvision_amd.train import Trainer
-    m = net_meta[tag]
+    net_kats, m = golden(tag)
     model = build(m["ctor"]).to(DEV)
-    tr = Trainer(model, class_weights=CE_W, lr=1e-3, decay=1e-6)
+    if m.get("dice"):
+        tr = Trainer(model, class_weights=DICE_W, lr=1e-3, decay=1e-6, use_dice=True)
+    else:
+        tr = Trainer(model, class_weights=CE_W, lr=1e-3, decay=1e-6)
     x, t = _t(net_kats[tag + "/x"]).to(DEV), _t(net_kats[tag + "/t"]).to(DEV)
     tr.step(x, t)
     met = tr.pop_metrics()

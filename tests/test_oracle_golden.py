@@ -86,14 +86,30 @@ def _cfg(ctor):
 SMALL = ["robo_s_2x48x64", "robo_l_1x48x64", "unet_s_2x48x64", "unet_l_1x32x48"]
 
 
-@pytest.mark.parametrize("tag", SMALL + ["robo_s_4x120x160"])
-def test_whole_net_step(net_kats, net_meta, tag):
-    m = net_meta[tag]
+DICE_V2 = ["v2_s_2x48x64", "v2_l_1x48x64", "robo_s_2x48x64_dice", "v2_s_2x48x64_dice", "robo_s_4x120x160_dice"]
+
+
+@pytest.mark.parametrize("name", ["dice5", "dice3", "dice5_sharp"])
+def test_dice_loss(dv_kats, name):
+    lg = _t(dv_kats[name + "/logits"]).requires_grad_(True)
+    t = _t(dv_kats[name + "/target"])
+    loss = O.dice_loss(lg, t, O.dice_weights(_t(dv_kats[name + "/weights"])))
+    assert torch.equal(loss.detach(), _t(dv_kats[name + "/loss"]))
+    loss.backward()
+    assert torch.equal(lg.grad, _t(dv_kats[name + "/dlogits"]))
+
+
+@pytest.mark.parametrize("tag", SMALL + ["robo_s_4x120x160"] + DICE_V2)
+def test_whole_net_step(golden, tag):
+    net_kats, m = golden(tag)
     torch.manual_seed(12345678)
     model = M.ROBO_UNet(**m["ctor"])
     sd = model.state_dict()
     assert sd_hash(sd) == m["sd_hash_init"]          # same construction order => same init as the reference
-    st = O.TrainState(sd, _cfg(m["ctor"]))
+    if m.get("dice"):
+        st = O.TrainState(sd, _cfg(m["ctor"]), ce_weight=(1, 2, 6, 3, 2), use_dice=True)      # train.py:309
+    else:
+        st = O.TrainState(sd, _cfg(m["ctor"]))
     x, t = O.synthetic_batch(m["B"], m["H"], m["W"])
     if (tag + "/x") in net_kats.files:
         assert torch.equal(x, _t(net_kats[tag + "/x"])) and torch.equal(t, _t(net_kats[tag + "/t"]))
