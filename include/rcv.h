@@ -83,7 +83,8 @@ enum {
   RCV_OP_DICE_FWD    = 23, /* weighted soft-Dice loss forward (+argmax, +#correct)   model.py:5-43 */
   RCV_OP_DICE_BWD    = 24, /* d loss / d logits of the Dice loss                                  */
   RCV_OP_NHWC_TO_NCHW= 25, /* out[n][c][p] = in[n][p][c] + bias[c], c < cout <= cin (3x3 classifier tail) */
-  RCV_OP_NCHW_TO_NHWC= 26  /* out[n][p][c] = c < cin ? in[n][c][p] : 0, cout channels per pixel     */
+  RCV_OP_NCHW_TO_NHWC= 26, /* out[n][p][c] = c < cin ? in[n][c][p] : 0, cout channels per pixel     */
+  RCV_OP_SGD         = 27  /* torch.optim.SGD(momentum, weight_decay) over a flat buffer (trainer.py:176-178) */
 };
 
 /* how an operand is produced from memory while it is staged (rcv_op.i[RCV_I_INMODE] etc.) */
@@ -244,6 +245,11 @@ int rcv_dice_bwd(rcv_handle* h, const float* logits, const int64_t* target, cons
  * mask loops of valid() (train.py:136-153).  counts is int32 [N][C][C] indexed [n][pred][label]; the call ADDS.   */
 int rcv_confusion(rcv_handle* h, const uint8_t* argmax, const int64_t* target, int N, int C, int H, int W,
                   int32_t* counts, void* stream);
+
+/* torch.optim.SGD.step (trainer.py:176-178,221): g = grad*grad_scale + weight_decay*p; buf = step==1 ? g : momentum*buf + g;
+ * p -= lr*buf.  lr_elem (may be NULL) gives a per-element learning rate (0 = parameter without a gradient: untouched). */
+int rcv_sgd_step(rcv_handle* h, float* param, const float* grad, float* momentum_buf, const float* lr_elem /*may be NULL*/,
+                 int64_t n, float lr, float momentum, float weight_decay, int step, float grad_scale, void* stream);
 
 int rcv_adam_l1_step(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                      const float* lr_elem /*may be NULL*/, int64_t n, float lr, float beta1, float beta2,

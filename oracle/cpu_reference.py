@@ -237,6 +237,70 @@ def labelprop_forward(sd: Dict[str, Tensor], x: Tensor, training: bool = False) 
     return F.conv2d(x, sd["classifier.weight"], sd["classifier.bias"])
 
 
+# ----------------------------------------------------------------------------------------
+# PB_FCN (model.py:126-142, 201-229, 269-309) and the trainer.py:205-221 step
+# ----------------------------------------------------------------------------------------
+def conv_pool(x, sd, prefix, training):
+    """model.py:126-142: relu(bn(pool(relu(conv1(x))))), conv1 dilated by 2, 'pool' a stride-2 3x3 conv."""
+    x = F.relu(F.conv2d(x, sd[prefix + ".conv1.weight"], None, padding=2, dilation=2))
+    x = F.conv2d(x, sd[prefix + ".pool.weight"], None, stride=2, padding=1)
+    return F.relu(_bn(x, sd, prefix + ".bn", training))
+
+
+def pb_fcn_forward(sd: Dict[str, Tensor], x: Tensor, noScale: bool, training: bool) -> Tensor:
+    """model.py:221-229 (DownSampler) + model.py:291-309 (PB_FCN, classify == 0)."""
+    def belly(v):
+        v = conv_pool(v, sd, "FCN.conv3", training)
+        for name in ("conv4", "conv5", "conv6", "conv7", "conv8"):
+            v = _cps(v, sd, "FCN." + name, 1, 2, 2, training)
+        return v
+
+    x0 = _cps(x, sd, "FCN.conv0", 1, 2, 2, training)
+    x1 = _cps(x0, sd, "FCN.conv1", 2, 1, 1, training)
+    x2 = conv_pool(x1, sd, "FCN.conv2", training)
+    if noScale:
+        x3 = conv_pool(x2, sd, "FCN.conv_ext", training)
+        x4 = belly(x3)
+        y = up_block(x4, sd, "up1", training) + x3
+        y = up_block(y, sd, "up2", training) + x2
+        y = up_block(y, sd, "up3", training) + x1
+        y = up_block(y, sd, "up4", training) + x0
+    else:
+        x3 = belly(x2)
+        y = up_block(x3, sd, "up1", training) + x2
+        y = up_block(y, sd, "up2", training) + x1
+        y = up_block(y, sd, "up3", training) + x0
+    return F.conv2d(y, sd["segmenter.classifier.weight"], sd["segmenter.classifier.bias"])
+
+
+class PBTrainState:
+    """trainer.py:135-178: CrossEntropyLoss2d([1,6,1.5,3,3]) and SGD(lr .1, momentum .5, weight_decay 1e-3) over all parameters
+    (those of the unused pooled classification head keep grad None and are skipped by SGD)."""
+
+    def __init__(self, sd: Dict[str, Tensor], noScale: bool, ce_weight: Sequence[float] = (1, 6, 1.5, 3, 3), lr: float = 1e-1,
+                 momentum: float = 0.5, weight_decay: float = 1e-3):
+        self.noScale = noScale
+        self.sd = {k: v.clone() for k, v in sd.items()}
+        self.names = param_names(self.sd)
+        for n in self.names:
+            self.sd[n].requires_grad_(True)
+        self.ce_weight = torch.tensor(list(ce_weight), dtype=torch.float32)
+        self.opt = torch.optim.SGD([{"params": [self.sd[n] for n in self.names]}], lr=lr, momentum=momentum, weight_decay=weight_decay)
+
+
+def pb_train_step(st: PBTrainState, imgs: Tensor, targets: Tensor, do_step: bool = True) -> Dict[str, object]:
+    """trainer.py:205-224."""
+    st.opt.zero_grad()
+    pred = pb_fcn_forward(st.sd, imgs, st.noScale, training=True)
+    loss = cross_entropy_2d(pred, targets, st.ce_weight)
+    loss.backward()
+    if do_step:
+        st.opt.step()
+    _, pred_class = torch.max(pred, 1)
+    return {"pred": pred.detach(), "loss": float(loss.item()), "pred_class": pred_class,
+            "correct": int(torch.sum(pred_class == targets).item())}
+
+
 def label_to_pred(label: Tensor, num_class: int) -> Tensor:
     """transform.py:172-183: +1 at the labelled class, -1 elsewhere, [B,C,H,W] float32."""
     B, H, W = label.shape

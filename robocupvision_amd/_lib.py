@@ -18,7 +18,7 @@ RCV_P__N = 20
 
 (OP_CONV, OP_TCONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_BWD, OP_COMBINE, OP_CLS_FWD,
  OP_CLS_BWD, OP_CE_FWD, OP_CE_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ADAM_L1, OP_MEMSET, OP_CONV1X1, OP_ADD_SLICE,
- OP_MATERIALIZE, OP_BWD_STATS, OP_CONFUSION, OP_DICE_FWD, OP_DICE_BWD, OP_NHWC_TO_NCHW, OP_NCHW_TO_NHWC) = range(1, 27)
+ OP_MATERIALIZE, OP_BWD_STATS, OP_CONFUSION, OP_DICE_FWD, OP_DICE_BWD, OP_NHWC_TO_NCHW, OP_NCHW_TO_NHWC, OP_SGD) = range(1, 28)
 
 LOAD_PLAIN, LOAD_AFFINE, LOAD_GRAD_ENC, LOAD_GRAD_DEC, LOAD_NCHW, LOAD_AFFINE_RELU = range(6)
 STATS_NONE, STATS_FWD, STATS_BWD_ENC, STATS_BWD_DEC = range(4)
@@ -41,7 +41,7 @@ EXPORTS = [
     "rcv_run_timed", "rcv_op_kernel_label",
     "rcv_conv3x3", "rcv_convT3x3s2", "rcv_wgrad3x3", "rcv_bn_finalize", "rcv_bn_backward", "rcv_maxpool2x2_fwd",
     "rcv_softmax_ce_argmax_fwd", "rcv_softmax_ce_bwd", "rcv_adam_l1_step", "rcv_confusion",
-    "rcv_dice_fwd", "rcv_dice_bwd",
+    "rcv_dice_fwd", "rcv_dice_bwd", "rcv_sgd_step",
 ]
 
 

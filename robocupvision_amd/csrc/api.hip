@@ -230,6 +230,18 @@ int rcv_confusion(rcv_handle* h, const uint8_t* argmax, const int64_t* target, i
   return rcv_run(h, &op, 1, stream);
 }
 
+int rcv_sgd_step(rcv_handle* h, float* param, const float* grad, float* momentum_buf, const float* lr_elem, int64_t n, float lr,
+                 float momentum, float weight_decay, int step, float grad_scale, void* stream) {
+  RCV_CHECK_ARG(n > 0 && n < ((int64_t)1 << 32), "rcv_sgd_step: n out of range");
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_SGD;
+  op.i[RCV_I_COUNT] = (int32_t)(uint32_t)n; op.i[RCV_I_AUX0] = step;
+  op.f[0] = lr; op.f[1] = momentum; op.f[2] = weight_decay; op.f[5] = grad_scale;
+  op.p[RCV_P_IN] = param; op.p[RCV_P_IN2] = (void*)grad; op.p[RCV_P_X0] = momentum_buf; op.p[RCV_P_X2] = (void*)lr_elem;
+  return rcv_run(h, &op, 1, stream);
+}
+
 int rcv_adam_l1_step(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* lr_elem,
                      int64_t n, float lr, float beta1, float beta2, float eps, float decay, int step, float grad_scale,
                      void* stream) {

@@ -682,6 +682,20 @@ __global__ void adam_l1_kernel(float* __restrict__ p, const float* __restrict__ 
   }
 }
 
+// torch.optim.SGD with momentum and weight decay (trainer.py:176-178), dampening 0, no nesterov
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, const float* __restrict__ lr_elem,
+                           size_t n, float lr, float momentum, float wd, float grad_scale, int first) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float step = lr_elem ? lr_elem[e] : lr;
+    if (step == 0.f) continue;                       // parameter outside the graph (grad None in PyTorch): untouched
+    const float pv = p[e];
+    const float gr = fmaf(wd, pv, g[e] * grad_scale);
+    const float b = first ? gr : fmaf(momentum, buf[e], gr);
+    buf[e] = b;
+    p[e] = pv - step * b;
+  }
+}
+
 __global__ void memset_kernel(float* __restrict__ p, size_t n) {
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) p[e] = 0.f;
 }
@@ -805,9 +819,9 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     static const char* names[] = {"?", "conv", "tconv", "wgrad", "wgrad_reduce", "pack", "bn_finalize", "bn_eval", "bn_bwd", "combine",
                                   "cls_fwd", "cls_bwd", "ce_fwd", "ce_bwd", "pool_fwd", "pool_bwd", "adam_l1", "memset", "conv1x1",
                                   "add_slice", "materialize", "bwd_stats", "confusion", "dice_fwd", "dice_bwd", "nhwc_to_nchw",
-                                  "nchw_to_nhwc"};
+                                  "nchw_to_nhwc", "sgd"};
     query->n_part = 0; query->n_split = 0; query->part_bytes = 0;
-    snprintf(query->label, sizeof(query->label), "%s", (op->kind > 0 && op->kind <= 26) ? names[op->kind] : "?");
+    snprintf(query->label, sizeof(query->label), "%s", (op->kind > 0 && op->kind <= 27) ? names[op->kind] : "?");
   }
   switch (op->kind) {
     case RCV_OP_PACK: {
@@ -972,6 +986,15 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       hipLaunchKernelGGL(adam_l1_kernel, dim3(stream_grid(h, n, 256)), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
                          (float*)op->p[RCV_P_X0], (float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], n, op->f[0], b1, b2, op->f[3],
                          op->f[4], op->f[5], bc1, bc2s);
+      break;
+    }
+    case RCV_OP_SGD: {
+      if (query) return RCV_OK;
+      const size_t n = (size_t)(uint32_t)op->i[RCV_I_COUNT];
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_X0] && n > 0 && op->i[RCV_I_AUX0] >= 1, "sgd: bad operand");
+      hipLaunchKernelGGL(sgd_kernel, dim3(stream_grid(h, n, 256)), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
+                         (float*)op->p[RCV_P_X0], (const float*)op->p[RCV_P_X2], n, op->f[0], op->f[1], op->f[2], op->f[5],
+                         op->i[RCV_I_AUX0] == 1 ? 1 : 0);
       break;
     }
     case RCV_OP_MEMSET: {

@@ -38,6 +38,16 @@ def _round_up(a: int, b: int) -> int:
     return (a + b - 1) // b * b
 
 
+def _conv_order(d: dict) -> str:
+    order = d.get("order", "relu_bn")
+    if d.get("bn") is None:
+        if order != "relu":
+            raise L.RcvError("a conv node without BatchNorm must be order='relu'")
+    elif order not in ("relu_bn", "bn_relu"):
+        raise L.RcvError("conv node order '%s' unknown" % order)
+    return order
+
+
 def select_buckets(marks, numel: int, n_buckets: int):
     """Pick <= n_buckets (ops_end, lo_offset) marks so that each bucket carries about numel/n_buckets gradients."""
     if not marks:
@@ -138,6 +148,15 @@ class Engine:
         self.graph = graph
         self.param_list = list(params)
         self.bn_modules = list(bn_modules)
+        used = set()
+        for d in graph["nodes"]:
+            for q in (d.get("weight"), d.get("bias")):
+                if q is not None:
+                    used.add(id(q))
+            if d.get("bn") is not None:
+                used.add(id(d["bn"].weight))
+                used.add(id(d["bn"].bias))
+        self.param_used = [id(p) in used for p in self.param_list]
         self.flat: Optional[FlatParams] = None
         self.plans: Dict[tuple, Plan] = {}
         self.device: Optional[torch.device] = None
@@ -267,7 +286,7 @@ class Engine:
             d = node.d
             if node.op == "conv":
                 src = ref(d["src"])
-                w, b, bn = d["weight"], d.get("bias"), d["bn"]
+                w, b, bn = d["weight"], d.get("bias"), d.get("bn")
                 Cout, Cin = w.shape[0], w.shape[1]
                 s, dil = d["stride"], d["dil"]
                 if Cin != src.C:
@@ -275,15 +294,21 @@ class Engine:
                 Ho, Wo = (src.H - 1) // s + 1, (src.W - 1) // s + 1
                 node.t["wp"] = add_pack(w, Cout, Cin, True, False)
                 r = self._alloc(plan, N, Ho, Wo, Cout)
-                bn_tensors(node, Cout)
-                relu_first = d.get("order", "relu_bn") == "relu_bn"
-                flags = (L.F_BIAS if b is not None else 0) | (L.F_RELU if relu_first else 0)
+                # order: 'relu_bn' = bn(relu(conv)) (Conv, model.py:115-116); 'bn_relu' = relu(bn(conv)) (ConvPoolSimple,
+                # model.py:175; the strided half of ConvPool, model.py:140-142); 'relu' = relu(conv), no BatchNorm (model.py:138-139)
+                order = _conv_order(d)
+                flags = (L.F_BIAS if b is not None else 0) | (L.F_RELU if order != "bn_relu" else 0)
                 op = L.make_op(L.OP_CONV, flags, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, ho=Ho, wo=Wo, stride=s, dil=dil,
                                inmode=src.load_mode, p_in_c=_ptr(src.consts), p_w=node.t["wp"].data_ptr(),
                                p_bias=_ptr(b), p_out=r.data_ptr())
                 op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
-                emit_bn_forward(node, bn, op, Cout, Ho, Wo)
-                node.out = Value("affine" if relu_first else "affine_relu", r, Cout, Ho, Wo, node.t["consts"], node)
+                if bn is not None:
+                    bn_tensors(node, Cout)
+                    emit_bn_forward(node, bn, op, Cout, Ho, Wo)
+                    node.out = Value("affine" if order == "relu_bn" else "affine_relu", r, Cout, Ho, Wo, node.t["consts"], node)
+                else:
+                    fwd.append(op)
+                    node.out = Value("plain", r, Cout, Ho, Wo, None, node)
             elif node.op == "pool":
                 src = ref(d["src"])
                 if src.H % 2 or src.W % 2:
@@ -402,8 +427,8 @@ class Engine:
                 if prod is None:
                     plan.input_grads[v.input_index] = v.grad
                     writer_op.i[L.RCV_I_STATS] = L.STATS_NONE
-                elif prod.op == "conv":
-                    writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_ENC
+                elif prod.op == "conv" and prod.d.get("bn") is not None:
+                    writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_ENC if _conv_order(prod.d) == "relu_bn" else L.STATS_BWD_DEC
                     writer_op.p[L.RCV_P_EPI_AUX] = v.buf.data_ptr()
                     writer_op.p[L.RCV_P_EPI_C] = prod.t["consts"].data_ptr()     # row 2 = batch mean
                 elif prod.op == "up" and not prod.d.get("concat"):
@@ -539,16 +564,22 @@ class Engine:
                         bwd.append(pop)
                 elif node.op == "conv":
                     out, src = node.out, ref(d["src"])
-                    w, b, bn = d["weight"], d.get("bias"), d["bn"]
+                    w, b, bn = d["weight"], d.get("bias"), d.get("bn")
                     Cout, Cin = w.shape[0], w.shape[1]
                     s, dil = d["stride"], d["dil"]
-                    if d.get("order", "relu_bn") != "relu_bn":
-                        raise L.RcvError("training of conv->BN->ReLU blocks is not built (inference only)")
+                    order = _conv_order(d)
                     if out.grad is None:
                         raise L.RcvError("conv node %d has no gradient producer" % node.idx)
-                    emit_bn_backward(node, bn, Cout, out.H, out.W)
-                    wop = L.make_op(L.OP_WGRAD, (L.F_BIAS if b is not None else 0), n=N, h=src.H, w=src.W, cin=Cin, ho=out.H, wo=out.W,
-                                    cout=Cout, stride=s, dil=dil, inmode=src.load_mode, inmode2=L.LOAD_GRAD_ENC,
+                    if bn is not None:
+                        emit_bn_backward(node, bn, Cout, out.H, out.W)
+                    else:       # relu(conv): the gradient load is the ReLU mask alone, v = r > 0 ? 1*g + 0 + 0*r : 0
+                        ones = self._zeros(plan, 5, Cout)
+                        ones[0].fill_(1.0)
+                        node.t["bconsts"] = ones
+                    gmode = L.LOAD_GRAD_DEC if order == "bn_relu" else L.LOAD_GRAD_ENC
+                    bias_grad = b is not None and order != "bn_relu"
+                    wop = L.make_op(L.OP_WGRAD, (L.F_BIAS if bias_grad else 0), n=N, h=src.H, w=src.W, cin=Cin, ho=out.H, wo=out.W,
+                                    cout=Cout, stride=s, dil=dil, inmode=src.load_mode, inmode2=gmode,
                                     p_in_c=_ptr(src.consts), p_in2=out.grad.data_ptr(), p_in2_aux=out.buf.data_ptr(),
                                     p_in2_c=node.t["bconsts"].data_ptr())
                     wop.p[L.RCV_P_IN] = (src.buf.data_ptr() if src.buf is not None else None)
@@ -558,12 +589,14 @@ class Engine:
                     bwd.append(wop)
                     bwd.append(L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cin, cout=Cout, nsplit=wop.i[L.RCV_I_NSPLIT],
                                          p_part=wop.p[L.RCV_P_PART], p_out=fl.grad_ptr(w),
-                                         p_bias=(fl.grad_ptr(b) if b is not None else 0)))
+                                         p_bias=(fl.grad_ptr(b) if bias_grad else 0)))
+                    if b is not None and not bias_grad:   # bias ahead of a BatchNorm: gradient is identically zero
+                        bwd.append(L.make_op(L.OP_MEMSET, 0, count=b.numel(), p_out=fl.grad_ptr(b)))
                     if src.needs_grad:
                         if s == 1:
                             node.t["wd"] = add_pack(w, Cout, Cin, False, True)
                             dop = L.make_op(L.OP_CONV, 0, n=N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=1, dil=dil,
-                                            inmode=L.LOAD_GRAD_ENC, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
+                                            inmode=gmode, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
                                             p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
                         else:
                             if src.H != 2 * out.H or src.W != 2 * out.W:
@@ -571,7 +604,7 @@ class Engine:
                             node.t["wd"] = add_pack(w, Cout, Cin, False, False, merged=use_merged(Cin))
                             dop = L.make_op(L.OP_TCONV, 0, n=N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=2, dil=1,
                                             aux0=int(use_merged(Cin)),
-                                            inmode=L.LOAD_GRAD_ENC, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
+                                            inmode=gmode, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
                                             p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
                         grad_target(src, dop, src.H, src.W)
                         bwd.append(dop)

@@ -21,7 +21,8 @@ from . import _lib as L
 from .engine import Engine
 
 __all__ = ["ROBO_UNet", "CrossEntropyLoss2d", "DiceLoss", "PB_FCN", "PB_FCN_2", "LabelProp", "Conv", "Pool", "LevelDown",
-           "upSampleTransposeConv", "UltClassifier", "ConvPoolSimple", "pruneModelNew", "count_zero_weights", "getParamSize"]
+           "upSampleTransposeConv", "UltClassifier", "ConvPoolSimple", "ConvPool", "DownSampler", "Classifier", "pruneModelNew",
+           "count_zero_weights", "getParamSize"]
 
 
 # ------------------------------------------------------------------------------------------
@@ -52,7 +53,8 @@ class _EngineFunction(torch.autograd.Function):
         for k in range(ctx.n_inputs):
             g = plan.input_grads[k] if ctx.needs_input_grad[3 + k] else None
             in_grads.append(g)
-        p_grads = [fl.grad_view(k) for k in range(ctx.n_params)]
+        # parameters the graph never reads (PB_FCN's pooled classification head) keep grad None, as under the reference's autograd
+        p_grads = [fl.grad_view(k) if eng.param_used[k] else None for k in range(ctx.n_params)]
         return (None, None, None, *in_grads, *p_grads)
 
 
@@ -137,7 +139,7 @@ class Conv(nn.Module, _BlockMixin):
 
 
 class ConvPoolSimple(nn.Module, _BlockMixin):
-    """relu(bn(conv(x))) with dilation, no bias (model.py:166-176); inference only here."""
+    """relu(bn(conv(x))) with dilation (model.py:166-176): LabelProp inference and the PB_FCN encoder."""
 
     def __init__(self, inplanes, planes, size, stride, padding, dilation, bias, *_ignored):
         super().__init__()
@@ -153,12 +155,37 @@ class ConvPoolSimple(nn.Module, _BlockMixin):
                 "stride": self.stride, "dil": self.dilation, "order": "bn_relu"}
 
     def _block_graph(self):
-        return {"inputs": [{"layout": "nhwc", "requires_grad": False}],
+        return {"inputs": [{"layout": "nhwc", "requires_grad": True}],
                 "nodes": [self._node(("in", 0)), {"op": "mat", "src": ("node", 0)}]}
 
     def forward(self, x):
-        if self.training:
-            raise L.RcvError("ConvPoolSimple (conv->BN->ReLU) is built for inference only; call .eval()")
+        return self._block_forward(x)
+
+
+class ConvPool(nn.Module, _BlockMixin):
+    """relu(bn(pool(relu(conv1(x))))): a dilated 3x3 conv, then a stride-2 3x3 conv as the 'pool' (model.py:126-142)."""
+
+    def __init__(self, inplanes, planes):
+        super().__init__()
+        self.relu = nn.ReLU()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, dilation=2, padding=2, bias=False)
+        self.pool = nn.Conv2d(planes, planes, kernel_size=3, padding=1, stride=2, bias=False)
+        self.bn = nn.BatchNorm2d(planes)
+
+    def _nodes(self, nodes: list, src):
+        nodes.append({"op": "conv", "src": src, "weight": self.conv1.weight, "bias": None, "bn": None, "stride": 1, "dil": 2,
+                      "order": "relu"})
+        nodes.append({"op": "conv", "src": ("node", len(nodes) - 1), "weight": self.pool.weight, "bias": None, "bn": self.bn,
+                      "stride": 2, "dil": 1, "order": "bn_relu"})
+        return ("node", len(nodes) - 1)
+
+    def _block_graph(self):
+        nodes: list = []
+        out = self._nodes(nodes, ("in", 0))
+        nodes.append({"op": "mat", "src": out})
+        return {"inputs": [{"layout": "nhwc", "requires_grad": True}], "nodes": nodes}
+
+    def forward(self, x):
         return self._block_forward(x)
 
 
@@ -552,8 +579,126 @@ class _OutOfScope(nn.Module):
                                   "outside the ROBO-UNet hot path this package implements (SURVEY.md section 8f)" % self._what)
 
 
-class PB_FCN(_OutOfScope):
-    _what = "PB_FCN"
+class DownSampler(nn.Module):
+    """PB_FCN encoder (model.py:201-237): children and construction order as the reference (state_dict / init parity)."""
+
+    def __init__(self, planes, noScale):
+        super().__init__()
+        self.noScale = noScale
+        outPlanes = planes // 4
+        self.conv0 = ConvPoolSimple(3, outPlanes, 3, 1, 2, 2, False)
+        self.conv1 = ConvPoolSimple(outPlanes, planes // 2, 3, 2, 1, 1, False)
+        self.conv2 = ConvPool(planes // 2, planes)
+        self.conv_ext = ConvPool(planes, planes) if noScale else None
+        self.conv3 = ConvPool(planes, planes * 2)
+        self.conv4 = ConvPoolSimple(planes * 2, planes * 4, 3, 1, 2, 2, False)
+        self.conv5 = ConvPoolSimple(planes * 4, planes * 4, 3, 1, 2, 2, False)
+        self.conv6 = ConvPoolSimple(planes * 4, planes * 4, 3, 1, 2, 2, False)
+        self.conv7 = ConvPoolSimple(planes * 4, planes * 4, 3, 1, 2, 2, False)
+        self.conv8 = ConvPoolSimple(planes * 4, planes * 2, 3, 1, 2, 2, False)
+
+    def _nodes(self, nodes: list, src):
+        """model.py:221-229; returns the references of (x4, x3, x2, x1, x0) (x4 is None without noScale)."""
+        def add(node):
+            nodes.append(node)
+            return ("node", len(nodes) - 1)
+
+        def belly(x):
+            x = self.conv3._nodes(nodes, x)
+            for m in (self.conv4, self.conv5, self.conv6, self.conv7, self.conv8):
+                x = add(m._node(x))
+            return x
+
+        x0 = add(self.conv0._node(src))
+        x1 = add(self.conv1._node(x0))
+        x2 = self.conv2._nodes(nodes, x1)
+        if self.noScale:
+            x3 = self.conv_ext._nodes(nodes, x2)
+            return belly(x3), x3, x2, x1, x0
+        return None, belly(x2), x2, x1, x0
+
+    def forward(self, x):
+        raise L.RcvError("DownSampler is executed as part of PB_FCN's graph; standalone use is not built")
+
+
+class Classifier(nn.Module):
+    """1x1 (kernelSize) classifier conv, optionally behind a max-pool (model.py:255-266).  Only the un-pooled segmentation
+    head runs here; the pooled patch-classification head only holds its parameters."""
+
+    def __init__(self, inplanes, num_classes, poolSize=0, kernelSize=1):
+        super().__init__()
+        self.classifier = nn.Conv2d(inplanes, num_classes, kernel_size=kernelSize, padding=kernelSize // 2)
+        self.pool = None
+        if poolSize > 1:
+            self.pool = nn.MaxPool2d(poolSize)
+
+    def _node(self, src):
+        if self.pool is not None:
+            raise L.RcvError("the pooled classification head of PB_FCN (classify=1) is outside the segmentation path")
+        return {"op": "cls", "src": src, "weight": self.classifier.weight, "bias": self.classifier.bias}
+
+    def forward(self, x):
+        raise L.RcvError("Classifier is executed as part of PB_FCN's graph; standalone use is not built")
+
+
+class PB_FCN(nn.Module):
+    """The older PB-FCN segmentation net of trainer.py (model.py:269-309): dilated conv->BN->ReLU encoder, three (four with
+    noScale) transposed-conv decoder blocks with skip adds, 1x1 segmenter.  classify=1 (patch classification through the
+    pooled head) is not built."""
+
+    def __init__(self, planes, num_classes, kernelSize, noScale, classify):
+        super().__init__()
+        if classify:
+            raise NotImplementedError("PB_FCN(classify=1) (patch classification) is outside the segmentation hot path")
+        self.noScale = noScale
+        self.classify = classify
+        self.img_shape = (240, 320) if self.noScale else (120, 160)
+        muliplier = 2 if noScale else 1
+        outPlanes = planes // 4
+        self.FCN = DownSampler(planes, noScale)
+        self.up1 = upSampleTransposeConv(planes * 2, planes)
+        self.up2 = upSampleTransposeConv(planes, planes // 2 * muliplier)
+        self.up3 = upSampleTransposeConv(planes // 2 * muliplier, outPlanes * muliplier)
+        self.up4 = upSampleTransposeConv(planes // 2, outPlanes) if noScale else None
+        self.classifier = Classifier(planes * 2, num_classes, poolSize=(2 if noScale else 4), kernelSize=kernelSize)
+        self.segmenter = Classifier(outPlanes, num_classes, kernelSize=kernelSize)
+
+    # graph of model.py:291-309 (classify == 0)
+    def _graph(self):
+        nodes: list = []
+        f4, f3, f2, f1, f0 = self.FCN._nodes(nodes, ("in", 0))
+
+        def up(layer, x, skip):
+            nodes.append(layer._node(x, skip))
+            return ("node", len(nodes) - 1)
+
+        if self.noScale:
+            x = up(self.up1, f4, f3)
+            x = up(self.up2, x, f2)
+            x = up(self.up3, x, f1)
+            x = up(self.up4, x, f0)
+        else:
+            x = up(self.up1, f3, f2)
+            x = up(self.up2, x, f1)
+            x = up(self.up3, x, f0)
+        nodes.append(self.segmenter._node(x))
+        return {"inputs": [{"layout": "nchw"}], "nodes": nodes}
+
+    def _get_engine(self) -> Engine:
+        eng = self.__dict__.get("_engine")
+        if eng is None:
+            eng = Engine(self._graph(), list(self.parameters()), _bn_modules(self))
+            self.__dict__["_engine"] = eng
+        return eng
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("PB_FCN expects float32 [B,3,H,W], got %s" % (tuple(x.shape),))
+        down = 16 if self.noScale else 8
+        if x.shape[2] % down or x.shape[3] % down:
+            raise ValueError("H and W must be multiples of %d (got %dx%d)" % (down, x.shape[2], x.shape[3]))
+        x = x.to(torch.float32).contiguous()
+        return _run_engine(self._get_engine(), self.training, [x])
 
 
 class PB_FCN_2(_OutOfScope):

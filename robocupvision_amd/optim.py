@@ -83,3 +83,49 @@ class AdamL1(torch.optim.Optimizer):
         """decay * sum|p| (what train.py:53 logs as `reg`), one reduction over the flat buffer."""
         _, fl = self._flat()
         return self.decay * fl.data.abs().sum()
+
+
+class SGD(torch.optim.Optimizer):
+    """torch.optim.SGD(lr, momentum, weight_decay) as trainer.py:176-178 configures it (dampening 0, no nesterov), fused into
+    ONE launch (RCV_OP_SGD) over the engine's flat parameter / gradient buffers.  Parameters the network graph never reads
+    (PB_FCN's pooled classification head) are left untouched, like parameters whose ``grad`` is None under torch.optim.SGD.
+    A ``torch.optim.Optimizer`` with one param group, so ReduceLROnPlateau (trainer.py:186) drives ``lr`` unchanged."""
+
+    def __init__(self, model, lr: float, momentum: float = 0.0, weight_decay: float = 0.0):
+        self.model = model
+        self.grad_scale = 1.0
+        self._buf: Optional[torch.Tensor] = None
+        self._lr_elem: Optional[torch.Tensor] = None
+        self._lr_key = None
+        self._t = 0
+        super().__init__([{"params": list(model.parameters())}], dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        eng = self.model._get_engine()
+        fl = eng.flat
+        if fl is None:
+            raise L.RcvError("SGD.step() before the first forward: the engine has not laid out the parameters yet")
+        if self._buf is None or self._buf.numel() != fl.numel or self._buf.device != fl.data.device:
+            self._buf = torch.zeros_like(fl.data)
+            self._t = 0
+        for k, p in enumerate(fl.params):
+            if p.grad is not None:
+                view = fl.grad_view(k)
+                if p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+        g = self.param_groups[0]
+        lr = float(g["lr"])
+        lr_elem_ptr = 0
+        if not all(eng.param_used):
+            if self._lr_key != lr:
+                t = torch.zeros_like(fl.data)
+                for k, p in enumerate(fl.params):
+                    if eng.param_used[k]:
+                        t[fl.offsets[k]:fl.offsets[k] + p.numel()] = lr
+                self._lr_elem, self._lr_key = t, lr
+            lr_elem_ptr = self._lr_elem.data_ptr()
+        self._t += 1
+        op = L.make_op(L.OP_SGD, 0, count=fl.numel, aux0=self._t, f0=lr, f1=g["momentum"], f2=g["weight_decay"], f5=self.grad_scale,
+                       p_in=fl.data.data_ptr(), p_in2=fl.grad.data_ptr(), p_x0=self._buf.data_ptr(), p_x2=lr_elem_ptr)
+        L.OpList([op]).run(eng.handle, torch.cuda.current_stream(fl.data.device).cuda_stream)

@@ -28,7 +28,7 @@ from .optim import AdamL1
 class Trainer:
     def __init__(self, model, class_weights: Optional[Sequence[float]] = (1, 10, 30, 10, 2), lr: float = 1e-3,
                  decay: float = 1e-6, transfer: int = 0, distributed: bool = False, overlap: bool = True,
-                 use_dice: bool = False):
+                 use_dice: bool = False, optimizer=None):
         self.model = model
         dev = next(model.parameters()).device
         if dev.type != "cuda":
@@ -41,7 +41,8 @@ class Trainer:
             self.criterion = DiceLoss(w).to(dev)
         else:
             self.criterion = CrossEntropyLoss2d(w).to(dev)
-        self.optimizer = AdamL1(model, lr=lr, decay=decay, transfer=transfer)
+        # default: the train.py optimizer (Adam over 5 groups + L1 term); trainer.py's PB_FCN path passes optim.SGD(model, ...)
+        self.optimizer = optimizer if optimizer is not None else AdamL1(model, lr=lr, decay=decay, transfer=transfer)
         self.metrics = torch.zeros(4, dtype=torch.float64, device=dev)     # loss, reg, correct, steps
         self.distributed = distributed
         self.world = 1
@@ -84,7 +85,7 @@ class Trainer:
         eng.grad_ready_cb = self._grad_ready if (self.distributed and (self.world > 1 or self.force_collectives)) else None
         ce.backward()
         with torch.no_grad():
-            reg = opt.l1_term()
+            reg = opt.l1_term() if hasattr(opt, "l1_term") else torch.zeros((), device=self.device)
             self.metrics += torch.stack([ce.detach().double() + reg.double(), reg.double(),
                                          crit.last_stats[2].double(), torch.ones((), dtype=torch.float64, device=self.device)])
         if self._pending is not None:

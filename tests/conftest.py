@@ -55,6 +55,18 @@ def dv_meta():
 
 
 @pytest.fixture(scope="session")
+def pb_kats():
+    """PB_FCN / trainer.py path (make_golden.py pbfcn)."""
+    return np.load(os.path.join(GOLDEN, "pbfcn.npz"))
+
+
+@pytest.fixture(scope="session")
+def pb_meta():
+    with open(os.path.join(GOLDEN, "pbfcn.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
 def golden(net_kats, net_meta, dv_kats, dv_meta):
     """tag -> (arrays, meta) across both whole-net fixture files."""
     def lookup(tag):

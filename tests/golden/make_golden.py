@@ -278,6 +278,104 @@ def dice_v2(ref, big=True):
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
+def pbfcn(ref, big=True):
+    """the PB_FCN / trainer.py path -- dilated conv->BN->ReLU encoder blocks in TRAINING mode, ConvPool, a whole
+    trainer.py:205-221 step (CrossEntropyLoss2d [1,6,1.5,3,3], SGD lr .1 momentum .5 weight_decay 1e-3), and the flat float64
+    parameter dump of paramSave.py."""
+    import io
+    import tempfile
+    out, meta = {}, {}
+    g = torch.Generator().manual_seed(4048)
+    torch.manual_seed(9)
+    block_kat(ref, out, "convpool_16_32", ref.ConvPool(16, 32), torch.randn(2, 16, 12, 16, generator=g), 400)
+    block_kat(ref, out, "convpool_32_64", ref.ConvPool(32, 64), torch.randn(2, 32, 10, 14, generator=g), 401)
+    block_kat(ref, out, "cpsT_16_16_d2", ref.ConvPoolSimple(16, 16, 3, 1, 2, 2, False), torch.randn(2, 16, 9, 11, generator=g), 402)
+    block_kat(ref, out, "cpsT_64_128_d2", ref.ConvPoolSimple(64, 128, 3, 1, 2, 2, False), torch.randn(2, 64, 6, 10, generator=g), 403)
+    block_kat(ref, out, "cpsT_8_16_s2", ref.ConvPoolSimple(8, 16, 3, 2, 1, 1, False), torch.randn(2, 8, 12, 16, generator=g), 404)
+
+    def step(tag, noScale, B, H, W, store_full):
+        torch.manual_seed(12345678)
+        model = ref.PB_FCN(32, 5, 1, noScale, 0)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        gg = torch.Generator().manual_seed(1)
+        x = torch.randn(B, 3, H, W, generator=gg)
+        t = torch.randint(0, 5, (B, H, W), generator=gg)
+        crit = ref.CrossEntropyLoss2d(torch.tensor([1, 6, 1.5, 3, 3], dtype=torch.float32))
+        opt = torch.optim.SGD([{'params': model.parameters()}], lr=1e-1, momentum=0.5, weight_decay=1e-3)
+        model.train()
+        losses = []
+        for it in range(2):          # two steps: the second one exercises the momentum buffer
+            opt.zero_grad()
+            pred = model(x)
+            loss = crit(pred, t)
+            loss.backward()
+            if it == 0:
+                pred0, gsum = pred.detach().clone(), grad_summary_some(model)
+                grads0 = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+                none_grads = [k for k, p in model.named_parameters() if p.grad is None]
+                gnorm = float(torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads0.values())))
+            opt.step()
+            losses.append(float(loss))
+            if it == 0:
+                sd1 = {k: v.clone() for k, v in model.state_dict().items()}
+        sd2 = model.state_dict()
+        _, pc = torch.max(pred0, 1)
+        top2 = torch.topk(pred0, 2, dim=1)[0]
+        margin = top2[:, 0] - top2[:, 1]
+        model.eval()
+        with torch.no_grad():
+            pred_eval = model(x)
+        meta[tag] = {
+            "noScale": noScale, "B": B, "H": H, "W": W, "threads": torch.get_num_threads(), "torch": torch.__version__,
+            "sd_hash_init": sd_hash(sd0), "sd_hash_after_step": sd_hash(sd1), "sd_hash_after_2_steps": sd_hash(sd2),
+            "loss": losses[0], "loss_step2": losses[1], "grad_norm": gnorm, "grad_summary": gsum, "none_grads": none_grads,
+            "logits_sum": float(pred0.double().sum()), "logits_abs_sum": float(pred0.double().abs().sum()),
+            "argmax_hist": [int((pc == c).sum()) for c in range(5)], "correct": int((pc == t).sum()),
+            "eval_logits_sum": float(pred_eval.double().sum()), "eval_logits_abs_sum": float(pred_eval.double().abs().sum()),
+            "param_after_step_sum": {k: float(v.double().sum()) for k, v in sd1.items() if v.dtype.is_floating_point},
+            "param_after_2_steps_sum": {k: float(v.double().sum()) for k, v in sd2.items() if v.dtype.is_floating_point},
+        }
+        out[tag + "/argmax"] = npy(pc).astype(np.uint8)
+        out[tag + "/near_tie_idx"] = np.nonzero(npy(margin).reshape(-1) < 1e-4)[0].astype(np.int32)
+        if store_full:
+            out[tag + "/x"] = npy(x); out[tag + "/t"] = npy(t).astype(np.int64)
+            out[tag + "/logits"] = npy(pred0); out[tag + "/eval_logits"] = npy(pred_eval)
+            for k, gr in grads0.items():
+                if gr.numel() <= 4096:
+                    out["%s/grad/%s" % (tag, k)] = npy(gr)
+                else:
+                    out["%s/grad_head/%s" % (tag, k)] = npy(gr.reshape(-1)[:64])
+            for k, v in sd1.items():
+                if "running" in k:
+                    out["%s/after/%s" % (tag, k)] = npy(v)
+        print(tag, "loss=%.8f / %.8f gnorm=%.8f hist=%s" % (losses[0], losses[1], gnorm, meta[tag]["argmax_hist"]))
+        return model
+
+    def grad_summary_some(model):
+        return {k: [float(p.grad.double().sum()), float(p.grad.double().abs().sum()), float(p.grad.double().norm())]
+                for k, p in model.named_parameters() if p.grad is not None}
+
+    model = step("pbfcn_s_2x48x64", False, 2, 48, 64, True)
+    step("pbfcn_l_1x64x96", True, 1, 64, 96, True)
+    if big:
+        step("pbfcn_s_4x120x160", False, 4, 120, 160, False)
+        step("pbfcn_l_2x240x320", True, 2, 240, 320, False)
+    # paramSave.saveParams on the twice-stepped small model: flat float64 dump in state_dict order
+    sys.path.insert(0, REF)
+    import paramSave
+    with tempfile.TemporaryDirectory() as td:
+        paramSave.saveParams(td, model.cpu(), "weights.dat", False)
+        flat = np.fromfile(os.path.join(td, "weights.dat"))
+        paramSave.saveParams(td, model.cpu(), "weights2.dat", True)
+        flat_skip = np.fromfile(os.path.join(td, "weights2.dat"))
+    meta["saveParams"] = {"model": "pbfcn_s_2x48x64 after 2 steps", "count": int(flat.size), "sha256": hashlib.sha256(flat.tobytes()).hexdigest(),
+                          "count_skip_classifier": int(flat_skip.size), "sha256_skip_classifier": hashlib.sha256(flat_skip.tobytes()).hexdigest(),
+                          "head": [float(v) for v in flat[:8]], "tail": [float(v) for v in flat[-8:]]}
+    np.savez_compressed(os.path.join(HERE, "pbfcn.npz"), **out)
+    with open(os.path.join(HERE, "pbfcn.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 def labelprop(ref):
     """LabelProp (config 5).  The class cannot be constructed at HEAD (8 args passed to a
     7-arg ConvPoolSimple.__init__), so the generator wraps the constructor to drop the extra
@@ -321,7 +419,7 @@ if __name__ == "__main__":
     torch.set_num_threads(THREADS)
     sys.path.insert(0, REF)
     import model as ref          # the reference, imported (never copied)
-    which = sys.argv[1:] or ["layers", "net", "lp", "dice_v2"]
+    which = sys.argv[1:] or ["layers", "net", "lp", "dice_v2", "pbfcn"]
     if "layers" in which:
         layer_kats(ref)
     if "net" in which:
@@ -330,3 +428,5 @@ if __name__ == "__main__":
         labelprop(ref)
     if "dice_v2" in which:
         dice_v2(ref)
+    if "pbfcn" in which:
+        pbfcn(ref)

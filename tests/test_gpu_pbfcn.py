@@ -1,0 +1,147 @@
+"""GPU: the PB_FCN / trainer.py path through the C ABI -- conv->BN->ReLU and ConvPool blocks in TRAINING
+mode, the whole trainer.py:205-221 step (CrossEntropyLoss2d + SGD with momentum and weight decay) -- against golden vectors of the
+imported reference (tests/golden/make_golden.py pbfcn) and the CPU oracle on the box.  Same bars as test_gpu_net.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sd_hash
+from oracle import cpu_reference as O
+import robocupvision_amd.model as M
+from robocupvision_amd.optim import SGD
+from robocupvision_amd.train import Trainer
+from test_gpu_blocks import close, _t, _load_block, _run_block
+from test_gpu_net import check_mask
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+PB_W = [1, 6, 1.5, 3, 3]          # trainer.py:135
+
+
+@pytest.mark.parametrize("name,cin,cout,s,d", [("cpsT_16_16_d2", 16, 16, 1, 2), ("cpsT_64_128_d2", 64, 128, 1, 2),
+                                               ("cpsT_8_16_s2", 8, 16, 2, 1)])
+def test_conv_bn_relu_block_training(pb_kats, name, cin, cout, s, d):
+    mod = _load_block(pb_kats, name, M.ConvPoolSimple(cin, cout, 3, s, d, d, False))
+    _run_block(pb_kats, name, mod)
+
+
+@pytest.mark.parametrize("name,cin,cout", [("convpool_16_32", 16, 32), ("convpool_32_64", 32, 64)])
+def test_conv_pool_block_training(pb_kats, name, cin, cout):
+    mod = _load_block(pb_kats, name, M.ConvPool(cin, cout))
+    _run_block(pb_kats, name, mod)
+
+
+def pb_step(model, x, t, opt=None):
+    crit = M.CrossEntropyLoss2d(torch.tensor(PB_W, dtype=torch.float32)).to(DEV)
+    if opt is None:
+        opt = torch.optim.SGD([{"params": model.parameters()}], lr=1e-1, momentum=0.5, weight_decay=1e-3)
+    model.train()
+    opt.zero_grad()
+    pred = model(x)
+    loss = crit(pred, t)
+    loss.backward()
+    grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in model.named_parameters()}
+    opt.step()
+    _, pc = torch.max(pred, 1)
+    return {"pred": pred.detach().clone(), "loss": float(loss), "pc": pc, "grads": grads, "opt": opt, "correct": int((pc == t).sum())}
+
+
+def _check_after(sd, sums, lr_steps):
+    for k, ref_sum in sums.items():
+        if "running" in k:
+            continue
+        got = float(sd[k].double().sum())
+        # SGD moves an element by lr*|g| per step; sums must agree to a small fraction of that scale
+        assert abs(got - ref_sum) <= 1e-3 * max(1.0, abs(ref_sum)) + 1e-4 * sd[k].numel() ** 0.5 * lr_steps, (k, got, ref_sum)
+
+
+@pytest.mark.parametrize("tag,fused", [("pbfcn_s_2x48x64", False), ("pbfcn_l_1x64x96", False), ("pbfcn_s_2x48x64", True)])
+def test_pb_fcn_step_vs_golden_small(pb_kats, pb_meta, tag, fused):
+    m = pb_meta[tag]
+    torch.manual_seed(12345678)
+    model = M.PB_FCN(32, 5, 1, m["noScale"], 0)
+    assert sd_hash(model.state_dict()) == m["sd_hash_init"]
+    model = model.to(DEV)
+    x, t = _t(pb_kats[tag + "/x"]).to(DEV), _t(pb_kats[tag + "/t"]).to(DEV)
+    opt = SGD(model, lr=1e-1, momentum=0.5, weight_decay=1e-3) if fused else None
+    res = pb_step(model, x, t, opt)
+    close(res["pred"], _t(pb_kats[tag + "/logits"]), tag + " logits")
+    assert abs(res["loss"] - m["loss"]) <= 1e-3 * abs(m["loss"])
+    check_mask(res["pc"], pb_kats[tag + "/argmax"], pb_kats[tag + "/near_tie_idx"], tag)
+    # the pooled classification head is outside the graph: grad None, exactly the reference's list
+    assert sorted(k for k, g in res["grads"].items() if g is None) == sorted(m["none_grads"])
+    for k, g in res["grads"].items():
+        if g is None or (k.startswith("up") and k.endswith("conv.bias")):
+            continue
+        key = "%s/grad/%s" % (tag, k)
+        if key in pb_kats.files:
+            close(g, _t(pb_kats[key]), "%s grad %s" % (tag, k), rtol=1e-3, floor=1.0)
+        else:
+            n_ = m["grad_summary"][k][2]
+            gn = float(g.double().norm())
+            assert abs(gn - n_) <= 1e-3 * n_ + 1e-7, (k, gn, n_)
+            close(g.reshape(-1)[:64], _t(pb_kats["%s/grad_head/%s" % (tag, k)]), "%s grad head %s" % (tag, k), rtol=1e-3, floor=1.0)
+    sd = model.state_dict()
+    for k in pb_kats.files:
+        if k.startswith(tag + "/after/"):
+            close(sd[k[len(tag) + 7:]], _t(pb_kats[k]), k)
+    _check_after(sd, m["param_after_step_sum"], 0.1)
+    # second step: momentum buffer in play
+    res2 = pb_step(model, x, t, res["opt"])
+    assert abs(res2["loss"] - m["loss_step2"]) <= 2e-3 * abs(m["loss_step2"]), (res2["loss"], m["loss_step2"])
+    _check_after(model.state_dict(), m["param_after_2_steps_sum"], 0.2)
+    model.eval()
+    with torch.no_grad():
+        pe = model(x)
+    close(pe, _t(pb_kats[tag + "/eval_logits"]), tag + " eval logits", rtol=5e-3)
+
+
+@pytest.mark.parametrize("tag", ["pbfcn_s_4x120x160", "pbfcn_l_2x240x320"])
+def test_pb_fcn_step_vs_golden_big(pb_kats, pb_meta, tag):
+    """trainer.py's shapes (160x120 and, with noScale, 320x240): checksums + the full arg-max mask, fused SGD through the Trainer."""
+    m = pb_meta[tag]
+    torch.manual_seed(12345678)
+    model = M.PB_FCN(32, 5, 1, m["noScale"], 0).to(DEV)
+    x, t = O.synthetic_batch(m["B"], m["H"], m["W"])
+    x, t = x.to(DEV), t.to(DEV)
+    tr = Trainer(model, class_weights=PB_W, optimizer=SGD(model, lr=1e-1, momentum=0.5, weight_decay=1e-3))
+    pred = tr.step(x, t).clone()
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    met = tr.pop_metrics()
+    assert abs(met["loss"] - m["loss"]) <= 1e-3 * abs(m["loss"])
+    las = float(pred.double().abs().sum())
+    assert abs(las - m["logits_abs_sum"]) <= 1e-3 * m["logits_abs_sum"]
+    assert abs(float(pred.double().sum()) - m["logits_sum"]) <= 1e-3 * m["logits_abs_sum"]
+    ndiff = check_mask(torch.max(pred, 1)[1], pb_kats[tag + "/argmax"], pb_kats[tag + "/near_tie_idx"], tag)
+    assert abs(met["correct_pixels"] - m["correct"]) <= ndiff
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())))
+    assert abs(gn - m["grad_norm"]) <= 1e-3 * m["grad_norm"], (gn, m["grad_norm"])
+    for k, g in grads.items():
+        if k.startswith("up") and k.endswith("conv.bias"):
+            continue
+        n32 = m["grad_summary"][k][2]
+        tol = 1e-2 if (k.endswith("bn.weight") or k.endswith("bn.bias")) else 2e-3
+        assert abs(float(g.double().norm()) - n32) <= tol * n32 + 1e-7, (k, float(g.double().norm()), n32)
+    tr.step(x, t)
+    assert abs(tr.pop_metrics()["loss"] - m["loss_step2"]) <= 2e-3 * abs(m["loss_step2"])
+
+
+def test_pb_fcn_vs_oracle_ragged():
+    """Non-golden shape / odd batch against the CPU oracle on the box."""
+    torch.manual_seed(12345678)
+    model = M.PB_FCN(32, 5, 1, False, 0)
+    st = O.PBTrainState(model.state_dict(), False)
+    x, t = O.synthetic_batch(3, 40, 72, seed=5)
+    ref = O.pb_train_step(st, x, t, do_step=False)
+    res = pb_step(model.to(DEV), x.to(DEV), t.to(DEV))
+    close(res["pred"], ref["pred"], "logits vs oracle")
+    assert abs(res["loss"] - ref["loss"]) <= 1e-3 * abs(ref["loss"])
+    margin = torch.topk(ref["pred"], 2, dim=1)[0]
+    near = np.nonzero(((margin[:, 0] - margin[:, 1]) < 1e-4).numpy().reshape(-1))[0]
+    check_mask(res["pc"], ref["pred_class"].numpy().astype(np.uint8), near, "mask vs oracle")
+    for n in st.names:
+        if st.sd[n].grad is None or (n.startswith("up") and n.endswith("conv.bias")):
+            continue
+        g, r = res["grads"][n].double().cpu(), st.sd[n].grad.double()
+        rel = float((g - r).norm() / (r.norm() + 1e-30))
+        assert rel <= 5e-3, "grad %s vs oracle: relative L2 error %.3e" % (n, rel)

@@ -128,6 +128,43 @@ def test_whole_net_step(golden, tag):
     assert np.array_equal(torch.max(pe, 1)[1].numpy().astype(np.uint8), net_kats[tag + "/eval_argmax"])
 
 
+@pytest.mark.parametrize("name", ["convpool_16_32", "convpool_32_64"])
+def test_conv_pool_block(pb_kats, name):
+    sd = _block_sd(pb_kats, name)
+    names = [k for k in sd if "running" not in k and "num_batches" not in k]
+    for k in names:
+        sd[k].requires_grad_(True)
+    x = _t(pb_kats[name + "/x"]).requires_grad_(True)
+    y = O.conv_pool(x, {("b." + k): v for k, v in sd.items()}, "b", True)
+    assert torch.equal(y.detach(), _t(pb_kats[name + "/y_train"]))
+    y.backward(_t(pb_kats[name + "/gy"]))
+    assert torch.equal(x.grad, _t(pb_kats[name + "/gx"]))
+    for k in names:
+        assert torch.equal(sd[k].grad, _t(pb_kats["%s/g/%s" % (name, k)])), k
+
+
+@pytest.mark.parametrize("tag", ["pbfcn_s_2x48x64", "pbfcn_l_1x64x96", "pbfcn_s_4x120x160"])
+def test_pb_fcn_steps(pb_kats, pb_meta, tag):
+    """Two trainer.py steps (SGD with momentum + weight decay) of the oracle hash like the reference's."""
+    m = pb_meta[tag]
+    torch.manual_seed(12345678)
+    model = M.PB_FCN(32, 5, 1, m["noScale"], 0)
+    sd = model.state_dict()
+    assert sd_hash(sd) == m["sd_hash_init"]
+    st = O.PBTrainState(sd, m["noScale"])
+    x, t = O.synthetic_batch(m["B"], m["H"], m["W"])
+    res = O.pb_train_step(st, x, t)
+    assert res["loss"] == m["loss"] and res["correct"] == m["correct"]
+    assert np.array_equal(res["pred_class"].numpy().astype(np.uint8), pb_kats[tag + "/argmax"])
+    if (tag + "/logits") in pb_kats.files:
+        assert torch.equal(res["pred"], _t(pb_kats[tag + "/logits"]))
+    assert sorted(n for n in st.names if st.sd[n].grad is None) == sorted(m["none_grads"])
+    assert sd_hash({k: v.detach() for k, v in st.sd.items()}) == m["sd_hash_after_step"]
+    res2 = O.pb_train_step(st, x, t)
+    assert res2["loss"] == m["loss_step2"]
+    assert sd_hash({k: v.detach() for k, v in st.sd.items()}) == m["sd_hash_after_2_steps"]
+
+
 def test_conv_macs_match_survey():
     # SURVEY.md 8(d): forward GFLOP per image = 2*MAC
     s = O.conv_macs(O.NetConfig(), 120, 160)[0]
