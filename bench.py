@@ -202,7 +202,8 @@ def main():
                            "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                            "share_of_kernel_time": round(d["ms"] / total_ms, 4),
                            "algorithmic_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1) if d["ms"] > 0 else 0.0}
-        tr, src = pmc_traffic(dom)
+        # the committed PMC pass is of the default workload: per-launch traffic of other shapes is not on disk
+        tr, src = pmc_traffic(dom) if args.workload == "robo_unet_640x480_bs32" and not args.batch else (None, None)
         if tr is not None:
             out["roofline"]["traffic"] = int(tr)
             out["roofline"]["traffic_source"] = "profiles/" + src

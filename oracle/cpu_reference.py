@@ -273,13 +273,28 @@ def pb_fcn_forward(sd: Dict[str, Tensor], x: Tensor, noScale: bool, training: bo
     return F.conv2d(y, sd["segmenter.classifier.weight"], sd["segmenter.classifier.bias"])
 
 
+def pb_fcn_2_forward(sd: Dict[str, Tensor], x: Tensor, training: bool, depth: int = 4, levels: int = 2, bellySize: int = 5) -> Tensor:
+    """model.py:416-458 (PB_FCN_2, classify False): the ROBO-UNet graph with a single-conv Level0 (model.py:426)."""
+    downs = [x]
+    downs.append(level_down(downs[-1], sd, "downPart.Level0", 1, False, False, training))
+    for i in range(depth - 1):
+        downs.append(level_down(downs[-1], sd, "downPart.Level%d" % (i + 1), levels, True, False, training))
+    b = level_down(downs[-1], sd, "PB.PB_1", bellySize - 1, False, False, training)
+    downs[-1] = level_down(b, sd, "PB.PB_2", 1, False, False, training)
+    up = downs[-1]
+    for i in range(depth - 1):
+        up = up_block(up, sd, "upPart.Up%d" % i, training) + downs[-(i + 2)]
+    return classifier(up, sd)
+
+
 class PBTrainState:
     """trainer.py:135-178: CrossEntropyLoss2d([1,6,1.5,3,3]) and SGD(lr .1, momentum .5, weight_decay 1e-3) over all parameters
     (those of the unused pooled classification head keep grad None and are skipped by SGD)."""
 
     def __init__(self, sd: Dict[str, Tensor], noScale: bool, ce_weight: Sequence[float] = (1, 6, 1.5, 3, 3), lr: float = 1e-1,
-                 momentum: float = 0.5, weight_decay: float = 1e-3):
+                 momentum: float = 0.5, weight_decay: float = 1e-3, v2: bool = False):
         self.noScale = noScale
+        self.v2 = v2                      # trainer.py:126-127: PB_FCN_2 instead of PB_FCN
         self.sd = {k: v.clone() for k, v in sd.items()}
         self.names = param_names(self.sd)
         for n in self.names:
@@ -291,7 +306,7 @@ class PBTrainState:
 def pb_train_step(st: PBTrainState, imgs: Tensor, targets: Tensor, do_step: bool = True) -> Dict[str, object]:
     """trainer.py:205-224."""
     st.opt.zero_grad()
-    pred = pb_fcn_forward(st.sd, imgs, st.noScale, training=True)
+    pred = pb_fcn_2_forward(st.sd, imgs, True) if st.v2 else pb_fcn_forward(st.sd, imgs, st.noScale, training=True)
     loss = cross_entropy_2d(pred, targets, st.ce_weight)
     loss.backward()
     if do_step:

@@ -258,14 +258,18 @@ class UltClassifier(nn.Module):
 
     def __init__(self, inplanes, nClass, pool, dropout=0.5, size=1):
         super().__init__()
-        if pool:
-            raise NotImplementedError("UltClassifier(pool=True) (patch classification) is outside the segmentation hot path")
         if size not in (1, 3):
             raise NotImplementedError("classifier kernel sizes 1 and 3 are built (got %d)" % size)
+        self.pooled = bool(pool)
         self.layers = nn.Sequential()
+        if pool:        # patch-classification head (PB_FCN_2.classifier): holds its parameters (state_dict / init parity), never executed
+            self.layers.add_module("Pool", nn.AdaptiveAvgPool2d(1))
+            self.layers.add_module("DO", nn.Dropout2d(dropout))
         self.layers.add_module("Class", nn.Conv2d(inplanes, nClass, size, padding=size // 2))
 
     def _node(self, src):
+        if self.pooled:
+            raise L.RcvError("the pooled classification head (classify=True) is outside the segmentation path")
         c = self.layers.Class
         return {"op": "cls", "src": src, "weight": c.weight, "bias": c.bias}
 
@@ -570,15 +574,6 @@ def getParamSize(x):
     return n
 
 
-class _OutOfScope(nn.Module):
-    _what = ""
-
-    def __init__(self, *a, **k):
-        super().__init__()
-        raise NotImplementedError("%s belongs to the older PB-FCN generation of the reference (trainer.py/tester.py) and is "
-                                  "outside the ROBO-UNet hot path this package implements (SURVEY.md section 8f)" % self._what)
-
-
 class DownSampler(nn.Module):
     """PB_FCN encoder (model.py:201-237): children and construction order as the reference (state_dict / init parity)."""
 
@@ -701,6 +696,31 @@ class PB_FCN(nn.Module):
         return _run_engine(self._get_engine(), self.training, [x])
 
 
-class PB_FCN_2(_OutOfScope):
-    _what = "PB_FCN_2"
+class PB_FCN_2(ROBO_UNet):
+    """trainer.py's v2 net (model.py:416-458, built at trainer.py:126-127): the ROBO-UNet graph with a one-conv Level0 plus a
+    pooled patch-classification head whose parameters stay outside the segmentation graph (grad None).  classify=True is not built."""
 
+    def __init__(self, classify, nClass=5, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128):
+        nn.Module.__init__(self)
+        if classify:
+            raise NotImplementedError("PB_FCN_2(classify=True) (patch classification) is outside the segmentation hot path")
+        self.classify = classify
+        self.numClass = nClass
+        self.planes = planes
+        self.v2 = False
+        self.img_shape = (120, 160)
+        maxDepth = planes * pow(2, depth - 1)
+        self.downPart = nn.ModuleList()
+        self.downPart.add_module("Level0", LevelDown(3, planes, 1, False))
+        for i in range(depth - 1):
+            nCh = planes * pow(2, i)
+            self.downPart.add_module("Level%d" % (i + 1), LevelDown(nCh, nCh * 2, levels, True))
+        self.PB = nn.Sequential()
+        self.PB.add_module("PB_1", LevelDown(maxDepth, bellyPlanes, bellySize - 1, False))
+        self.PB.add_module("PB_2", LevelDown(bellyPlanes, maxDepth, 1, False))
+        self.upPart = nn.ModuleList()
+        for i in range(depth - 1):
+            nCh = planes * pow(2, depth - 1 - i)
+            self.upPart.add_module("Up%d" % i, upSampleTransposeConv(nCh, nCh // 2))
+        self.classifier = UltClassifier(maxDepth, nClass, True)
+        self.segmenter = UltClassifier(planes, nClass, False)

@@ -293,9 +293,9 @@ def pbfcn(ref, big=True):
     block_kat(ref, out, "cpsT_64_128_d2", ref.ConvPoolSimple(64, 128, 3, 1, 2, 2, False), torch.randn(2, 64, 6, 10, generator=g), 403)
     block_kat(ref, out, "cpsT_8_16_s2", ref.ConvPoolSimple(8, 16, 3, 2, 1, 1, False), torch.randn(2, 8, 12, 16, generator=g), 404)
 
-    def step(tag, noScale, B, H, W, store_full):
+    def step(tag, noScale, B, H, W, store_full, v2=False):
         torch.manual_seed(12345678)
-        model = ref.PB_FCN(32, 5, 1, noScale, 0)
+        model = ref.PB_FCN_2(False, nClass=5) if v2 else ref.PB_FCN(32, 5, 1, noScale, 0)      # trainer.py:126-129
         sd0 = {k: v.clone() for k, v in model.state_dict().items()}
         gg = torch.Generator().manual_seed(1)
         x = torch.randn(B, 3, H, W, generator=gg)
@@ -326,7 +326,7 @@ def pbfcn(ref, big=True):
         with torch.no_grad():
             pred_eval = model(x)
         meta[tag] = {
-            "noScale": noScale, "B": B, "H": H, "W": W, "threads": torch.get_num_threads(), "torch": torch.__version__,
+            "noScale": noScale, "v2": v2, "B": B, "H": H, "W": W, "threads": torch.get_num_threads(), "torch": torch.__version__,
             "sd_hash_init": sd_hash(sd0), "sd_hash_after_step": sd_hash(sd1), "sd_hash_after_2_steps": sd_hash(sd2),
             "loss": losses[0], "loss_step2": losses[1], "grad_norm": gnorm, "grad_summary": gsum, "none_grads": none_grads,
             "logits_sum": float(pred0.double().sum()), "logits_abs_sum": float(pred0.double().abs().sum()),
@@ -357,6 +357,7 @@ def pbfcn(ref, big=True):
 
     model = step("pbfcn_s_2x48x64", False, 2, 48, 64, True)
     step("pbfcn_l_1x64x96", True, 1, 64, 96, True)
+    step("pbfcn2_s_2x48x64", False, 2, 48, 64, True, v2=True)
     if big:
         step("pbfcn_s_4x120x160", False, 4, 120, 160, False)
         step("pbfcn_l_2x240x320", True, 2, 240, 320, False)

@@ -55,11 +55,12 @@ def _check_after(sd, sums, lr_steps):
         assert abs(got - ref_sum) <= 1e-3 * max(1.0, abs(ref_sum)) + 1e-4 * sd[k].numel() ** 0.5 * lr_steps, (k, got, ref_sum)
 
 
-@pytest.mark.parametrize("tag,fused", [("pbfcn_s_2x48x64", False), ("pbfcn_l_1x64x96", False), ("pbfcn_s_2x48x64", True)])
+@pytest.mark.parametrize("tag,fused", [("pbfcn_s_2x48x64", False), ("pbfcn_l_1x64x96", False), ("pbfcn_s_2x48x64", True),
+                                       ("pbfcn2_s_2x48x64", True)])
 def test_pb_fcn_step_vs_golden_small(pb_kats, pb_meta, tag, fused):
     m = pb_meta[tag]
     torch.manual_seed(12345678)
-    model = M.PB_FCN(32, 5, 1, m["noScale"], 0)
+    model = M.PB_FCN_2(False, nClass=5) if m["v2"] else M.PB_FCN(32, 5, 1, m["noScale"], 0)
     assert sd_hash(model.state_dict()) == m["sd_hash_init"]
     model = model.to(DEV)
     x, t = _t(pb_kats[tag + "/x"]).to(DEV), _t(pb_kats[tag + "/t"]).to(DEV)
@@ -71,7 +72,7 @@ def test_pb_fcn_step_vs_golden_small(pb_kats, pb_meta, tag, fused):
     # the pooled classification head is outside the graph: grad None, exactly the reference's list
     assert sorted(k for k, g in res["grads"].items() if g is None) == sorted(m["none_grads"])
     for k, g in res["grads"].items():
-        if g is None or (k.startswith("up") and k.endswith("conv.bias")):
+        if g is None or (k.startswith("up") and k.endswith("conv.bias")):       # up1.. (PB_FCN) / upPart.Up* (PB_FCN_2)
             continue
         key = "%s/grad/%s" % (tag, k)
         if key in pb_kats.files:

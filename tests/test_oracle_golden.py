@@ -143,15 +143,15 @@ def test_conv_pool_block(pb_kats, name):
         assert torch.equal(sd[k].grad, _t(pb_kats["%s/g/%s" % (name, k)])), k
 
 
-@pytest.mark.parametrize("tag", ["pbfcn_s_2x48x64", "pbfcn_l_1x64x96", "pbfcn_s_4x120x160"])
+@pytest.mark.parametrize("tag", ["pbfcn_s_2x48x64", "pbfcn_l_1x64x96", "pbfcn_s_4x120x160", "pbfcn2_s_2x48x64"])
 def test_pb_fcn_steps(pb_kats, pb_meta, tag):
     """Two trainer.py steps (SGD with momentum + weight decay) of the oracle hash like the reference's."""
     m = pb_meta[tag]
     torch.manual_seed(12345678)
-    model = M.PB_FCN(32, 5, 1, m["noScale"], 0)
+    model = M.PB_FCN_2(False, nClass=5) if m["v2"] else M.PB_FCN(32, 5, 1, m["noScale"], 0)
     sd = model.state_dict()
     assert sd_hash(sd) == m["sd_hash_init"]
-    st = O.PBTrainState(sd, m["noScale"])
+    st = O.PBTrainState(sd, m["noScale"], v2=m["v2"])
     x, t = O.synthetic_batch(m["B"], m["H"], m["W"])
     res = O.pb_train_step(st, x, t)
     assert res["loss"] == m["loss"] and res["correct"] == m["correct"]
