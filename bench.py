@@ -219,9 +219,15 @@ def main():
                 print("%-28s launches %3d  ms %8.3f  %5.1f%%  %7.2f TF/s  %8.1f GB/s" %
                       (k, a["launches"], a["ms"], 100 * a["ms"] / total_ms, tf, gb), file=sys.stderr)
             if os.environ.get("RCV_BENCH_ROWS"):
-                for r in rows:
-                    print("%-28s ms %8.4f  %7.2f TF/s %8.1f GB/s" % (r["label"], r["ms"], r["flops"] / max(r["ms"], 1e-9) / 1e9,
-                                                                   r["bytes"] / max(r["ms"], 1e-9) / 1e6), file=sys.stderr)
+                # per op: measured vs the per-op roofline bound max(FLOP/157.3T, bytes/8T); sorted by the gap
+                tot_gap = 0.0
+                for r in sorted(rows, key=lambda r: -(r["ms"] - max(r["flops"] / 157.3e9, r["bytes"] / 8e9))):
+                    lb = max(r["flops"] / 157.3e9, r["bytes"] / 8e9)
+                    tot_gap += r["ms"] - lb
+                    print("%s %-26s %-24s ms %7.4f  bound %7.4f  gap %7.4f  %6.2f TF/s %7.1f GB/s" %
+                          ("B" if r["bwd"] else "F", r["label"], r["shape"], r["ms"], lb, r["ms"] - lb, r["flops"] / max(r["ms"], 1e-9) / 1e9,
+                           r["bytes"] / max(r["ms"], 1e-9) / 1e6), file=sys.stderr)
+                print("sum of per-op bounds %.3f ms, sum of gaps %.3f ms" % (sum(r["ms"] for r in rows) - tot_gap, tot_gap), file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctor, H, W, dice=args.dice)
     if rank == 0:

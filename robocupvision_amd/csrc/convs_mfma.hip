@@ -301,13 +301,20 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
 // host side
 // --------------------------------------------------------------------------------------------
 static const int kNarrowXMAX = 8;
-static const int kNarrowWN = 5;
+// pixel blocks per wave (WN) the kernel is instantiated for, per staged channel count: small WN for layers whose tile is
+// capped by the prefetch registers (stride-2 and 32-channel inputs), so that no MFMA slot runs on padding pixels
+static const int kNarrowWNs[] = {5, 3, 2};
+static inline bool narrow_wn_built(int WN, int CK, int WM) {
+  if (WM == 4) return WN == 3 && CK >= 16;       // merged transposed conv with 16 real output channels (WN = 5 measured slower: 80 accumulator registers)
+  return WN == 5 || (WN == 3 && CK >= 8) || (WN == 2 && CK == 16);
+}
 
 bool convs_supported(const rcv_handle* h, const rcv_op* op, int kind, int CinP, int CoutV) {
   (void)h; (void)op;
   if (getenv("RCV_NO_NARROW")) return false;
   if (kind == KIND_TPHASE) return false;
   if (!(CinP == 4 || CinP == 8 || CinP == 16 || CinP == 32)) return false;
+  if (kind == KIND_TMERGED && (CinP == 16 || CinP == 32) && round_up(CoutV, 16) == 64 && !getenv("RCV_NO_NARROW4")) return true;   // 4 x 16 virtual channels
   return round_up(CoutV, 16) <= 32;
 }
 
@@ -321,36 +328,42 @@ int convs_make_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* p
   pl->CK = CinP;
   pl->CoutV = kind == KIND_TMERGED ? 4 * Cout : Cout;
   pl->CoutP = round_up(pl->CoutV, 16);
-  pl->WM = pl->CoutP / 16; pl->WN = kNarrowWN; pl->XMAX = kNarrowXMAX;
-  const int PIX = 64 * pl->WN;
+  pl->WM = pl->CoutP / 16; pl->XMAX = kNarrowXMAX;
   const int Q = CinP / 4;
   const int cap = (256 / Q) * pl->XMAX;
   const int TH = kind == KIND_GATHER ? Ho : H, TW = kind == KIND_GATHER ? Wo : W;
-  // tile: rows x cols within PIX pixels and the prefetch capacity; minimise staged pixels + a small idle-lane penalty
+  const int ntaps = kind == KIND_GATHER ? 9 : 4;
+  // tile: rows x cols within 64*WN pixel slots and the prefetch capacity.  Cost model per tile (SIMD cycles): the MFMA phase
+  // (every slot costs, used or not), staging the halo, a fixed part (barriers, prefetch issue, epilogue address work).
   double best = -1.0;
-  int ovR = 0, ovW = 0;
-  if (const char* ev = getenv("RCV_CONVS_TILE")) sscanf(ev, "%d,%d", &ovR, &ovW);
-  for (int nx = 1; nx <= TW; ++nx) {
-    const int wt = ceil_div(TW, nx);
-    if (wt > PIX) continue;
-    if (nx > 1 && wt < 8) break;
-    for (int r = PIX / wt < TH ? PIX / wt : TH; r >= 1; --r) {
-      int ih, iw;
-      tile_halo(kind, r, wt, s, d, &ih, &iw);
-      if (ih * iw > cap) continue;
-      if (ovR > 0 && !(r == ovR && wt == ovW)) continue;
-      const int rb = ceil_div(TH, ceil_div(TH, r));
-      tile_halo(kind, rb, wt, s, d, &ih, &iw);
-      const double tiles = (double)ceil_div(TW, wt) * ceil_div(TH, rb);
-      const double score = tiles * ((double)ih * iw + 0.25 * PIX + 64.0);
-      if (best < 0 || score < best) { best = score; pl->R = rb; pl->Wt = wt; }
-      break;
+  int ovR = 0, ovW = 0, ovWN = 0;
+  if (const char* ev = getenv("RCV_CONVS_TILE")) sscanf(ev, "%d,%d,%d", &ovR, &ovW, &ovWN);
+  for (int WN : kNarrowWNs) {
+    if (!narrow_wn_built(WN, CinP, pl->WM) || (ovWN > 0 && WN != ovWN)) continue;
+    const int PIX = 64 * WN;
+    for (int nx = 1; nx <= TW; ++nx) {
+      const int wt = ceil_div(TW, nx);
+      if (wt > PIX) continue;
+      if (nx > 1 && wt < 8) break;
+      for (int r = PIX / wt < TH ? PIX / wt : TH; r >= 1; --r) {
+        int ih, iw;
+        tile_halo(kind, r, wt, s, d, &ih, &iw);
+        if (ih * iw > cap) continue;
+        if (ovR > 0 && !(r == ovR && wt == ovW)) continue;
+        const int rb = ceil_div(TH, ceil_div(TH, r));
+        tile_halo(kind, rb, wt, s, d, &ih, &iw);
+        const double tiles = (double)ceil_div(TW, wt) * ceil_div(TH, rb);
+        const double mfma = 32.0 * WN * pl->WM * ntaps * (CinP / 4);
+        const double stage = 24.0 * ceil_div(ih * iw * Q, 256);
+        const double score = tiles * (mfma + stage + 1200.0 + 60.0 * WN * pl->WM);
+        if (best < 0 || score < best) { best = score; pl->R = rb; pl->Wt = wt; pl->WN = WN; }
+        break;
+      }
     }
   }
   RCV_CHECK_ARG(best >= 0, "conv (narrow): no tile fits %dx%d", TH, TW);
   pl->tiles_x = ceil_div(TW, pl->Wt); pl->tiles_y = ceil_div(TH, pl->R);
   tile_halo(kind, pl->R, pl->Wt, s, d, &pl->IH, &pl->IW);
-  const int ntaps = kind == KIND_GATHER ? 9 : 4;
   const int S = CinP == 32 ? 37 : CinP + 1;
   pl->wl_floats = round_up(ntaps * CinP * (pl->CoutP + 16), 4);
   pl->xl_floats = round_up(pl->IH * pl->IW * S, 4);
@@ -369,9 +382,9 @@ int convs_make_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* p
   return RCV_OK;
 }
 
-template <int WM, int CK, int KIND, bool TWO>
+template <int WM, int WN, int CK, int KIND, bool TWO>
 static int convs_launch_inst(const ConvPlan& pl, const ConvArgs& a, hipStream_t s) {
-  auto kern = convs_mfma_kernel<WM, kNarrowWN, CK, KIND, kNarrowXMAX, TWO>;
+  auto kern = convs_mfma_kernel<WM, WN, CK, KIND, kNarrowXMAX, TWO>;
   static size_t configured = 0;
   if (pl.lds > configured) {
     RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
@@ -382,22 +395,41 @@ static int convs_launch_inst(const ConvPlan& pl, const ConvArgs& a, hipStream_t 
   return RCV_OK;
 }
 
-template <int WM, int CK, int KIND>
+template <int WM, int WN, int CK, int KIND>
 static int convs_launch_two(const ConvPlan& pl, const ConvArgs& a, bool two, hipStream_t s) {
-  return two ? convs_launch_inst<WM, CK, KIND, true>(pl, a, s) : convs_launch_inst<WM, CK, KIND, false>(pl, a, s);
+  return two ? convs_launch_inst<WM, WN, CK, KIND, true>(pl, a, s) : convs_launch_inst<WM, WN, CK, KIND, false>(pl, a, s);
 }
 
 template <int WM, int KIND>
 static int convs_launch_ck(const ConvPlan& pl, const ConvArgs& a, bool two, hipStream_t s) {
-  switch (pl.CK) {
-    case 4: return convs_launch_two<WM, 4, KIND>(pl, a, two, s);
-    case 8: return convs_launch_two<WM, 8, KIND>(pl, a, two, s);
-    case 16: return convs_launch_two<WM, 16, KIND>(pl, a, two, s);
-    default: return convs_launch_two<WM, 32, KIND>(pl, a, two, s);
+  // instantiated (WN, CK) pairs: keep in step with narrow_wn_built()
+  switch (pl.WN * 100 + pl.CK) {
+    case 504: return convs_launch_two<WM, 5, 4, KIND>(pl, a, two, s);
+    case 508: return convs_launch_two<WM, 5, 8, KIND>(pl, a, two, s);
+    case 516: return convs_launch_two<WM, 5, 16, KIND>(pl, a, two, s);
+    case 532: return convs_launch_two<WM, 5, 32, KIND>(pl, a, two, s);
+    case 308: return convs_launch_two<WM, 3, 8, KIND>(pl, a, two, s);
+    case 316: return convs_launch_two<WM, 3, 16, KIND>(pl, a, two, s);
+    case 332: return convs_launch_two<WM, 3, 32, KIND>(pl, a, two, s);
+    case 216: return convs_launch_two<WM, 2, 16, KIND>(pl, a, two, s);
+    default:
+      rcv_set_error("conv (narrow): no kernel for WN=%d CK=%d", pl.WN, pl.CK);
+      return RCV_E_ARG;
+  }
+}
+
+static int convs_launch_wm4(const ConvPlan& pl, const ConvArgs& a, bool two, hipStream_t s) {
+  switch (pl.WN * 100 + pl.CK) {
+    case 316: return convs_launch_two<4, 3, 16, KIND_TMERGED>(pl, a, two, s);
+    case 332: return convs_launch_two<4, 3, 32, KIND_TMERGED>(pl, a, two, s);
+    default:
+      rcv_set_error("conv (narrow): no 64-channel kernel for WN=%d CK=%d", pl.WN, pl.CK);
+      return RCV_E_ARG;
   }
 }
 
 int convs_launch(const ConvPlan& pl, const ConvArgs& a, bool two, hipStream_t s) {
+  if (pl.WM == 4) return convs_launch_wm4(pl, a, two, s);
   if (pl.kind == KIND_GATHER) return pl.WM == 1 ? convs_launch_ck<1, KIND_GATHER>(pl, a, two, s) : convs_launch_ck<2, KIND_GATHER>(pl, a, two, s);
   return pl.WM == 1 ? convs_launch_ck<1, KIND_TMERGED>(pl, a, two, s) : convs_launch_ck<2, KIND_TMERGED>(pl, a, two, s);
 }

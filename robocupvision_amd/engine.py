@@ -704,7 +704,8 @@ class Engine:
                 elif op.kind == L.OP_WGRAD:
                     flops = 2.0 * 9 * cin * cout * n * ho * wo
                     nbytes = 4.0 * (n * h * w * cin * two(i[L.RCV_I_INMODE]) + n * ho * wo * cout * two(i[L.RCV_I_INMODE2]))
-                rows.append({"label": labels[k], "kind": int(op.kind), "ms": acc[k] / reps, "flops": flops, "bytes": nbytes})
+                rows.append({"label": labels[k], "kind": int(op.kind), "ms": acc[k] / reps, "flops": flops, "bytes": nbytes,
+                             "shape": "%dx%dx%d %d->%d s%d" % (n, h, w, cin, cout, i[L.RCV_I_STRIDE]), "bwd": lst is not plan.fwd})
         return rows
 
     def backward(self, dlogits: torch.Tensor):
