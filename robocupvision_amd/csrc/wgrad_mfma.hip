@@ -89,8 +89,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
   constexpr int CAT = WN * WAVES_N * 16;
   constexpr bool FOLD = NBF > 0;
   constexpr int NACC = FOLD ? NBF : 9 * WN;
-  constexpr int QP = CBT / 4;
-  constexpr int STEPP = NT / QP;
+  constexpr int QPMAX = CBT / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bufsz = a.pl_floats + a.gl_floats;            // two (P, G) tile buffers
 
@@ -110,6 +109,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
   const int ctile = bl % a.nctiles, split = bl / a.nctiles;
   const int cb_tile = ctile / n_ca_tiles, ca_tile = ctile % n_ca_tiles;
   const int cb0 = cb_tile * CBT, ca0 = ca_tile * CAT;
+  // 16-byte quads of the pointwise operand that hold real channels (a power of two, so that it divides the thread count): with 8
+  // channels in a 16-wide tile only half the staging threads would otherwise have a load to issue
+  int QP = QPMAX;
+  while (QP > 1 && (QP / 2) * 4 >= a.CB - cb0) QP /= 2;
+  const int STEPP = NT / QP;
   const int s = a.stride, d = a.dil;
   const int QG = FOLD ? (a.CA + 3) / 4 : CAT / 4;        // 16-byte quads per staged gathered pixel
   const int STEPG = NT / QG;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
   const bool p_two = a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC;
   const bool g_two = a.g_mode == RCV_LOAD_GRAD_ENC || a.g_mode == RCV_LOAD_GRAD_DEC;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int UNR = 4;
+  constexpr int UNR = (!SPEC && FOLD) ? 8 : 4;      // folded (<= 8 channel) tiles are HBM bound: more loads in flight
   auto stage = [&](int tile, float* pl, float* gl) {
     int t = tile;
     const int tx_i = t % a.tiles_x;
@@ -285,6 +289,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
     }
   };
   const bool do_stage = !(a.dbg & RCV_F_DBG_NOSTAGE), do_mfma = !(a.dbg & RCV_F_DBG_NOMFMA);
+  if (QP < QPMAX) {      // the channel columns no staging thread writes must read as zero
+    const int nfl = (SPEC ? 2 : 1) * bufsz;
+    for (int e = threadIdx.x; e < nfl; e += blockDim.x) smem[e] = 0.f;
+    __syncthreads();
+  }
   if (SPEC) {
     // producer waves stage tile i+1 into the other buffer while the consumer waves contract tile i: one barrier per tile
     if (producer && split < a.ntiles && do_stage) stage(split, smem, smem + a.pl_floats);
@@ -530,6 +539,9 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   pl->nsplit = nsplit;
   pl->grid = dim3(nsplit * ctiles, 1, 1);
   pl->nctiles = ctiles;
+  if (getenv("RCV_DEBUG_PLAN"))
+    fprintf(stderr, "wgrad plan: tile %d  R=%d Wt=%d (%d px) IHxIW=%dx%d  ntiles=%d nsplit=%d ctiles=%d lds=%zu\n", pl->tile, pl->R, pl->Wt,
+            pl->R * pl->Wt4, pl->IH, pl->IW, ntiles, nsplit, ctiles, pl->lds);
   return RCV_OK;
 }
 

@@ -1,0 +1,9 @@
+#!/bin/bash
+B="python scripts/bench_op.py"
+run() { RCV_WGRAD_OCC=2 $B "$@" 2>/dev/null | tail -1 | sed "s/^/occ2 /"; $B "$@" 2>/dev/null | tail -1 | sed "s/^/occ3 /"; }
+run wgrad 32 480 640 3 8 --mode nchw --mode2 grad_enc
+run wgrad 32 480 640 8 16 --stride 2 --mode affine --mode2 grad_enc
+run wgrad 32 480 640 8 16 --stride 2 --mode grad_dec --mode2 affine
+run wgrad 32 240 320 16 16 --mode affine --mode2 grad_enc
+run wgrad 32 480 640 8 8 --mode affine --mode2 grad_enc
+run wgrad 32 240 320 8 16 --mode affine --mode2 grad_enc
