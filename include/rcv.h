@@ -114,6 +114,8 @@ enum {
 #define RCV_F_TRANSPOSED_SRC 32u /* PACK / WGRAD_REDUCE: parameter is [Cin][Cout][3][3] (convT)  */
 #define RCV_F_ARGMAX    64u   /* CE_FWD: also write argmax mask and count correct pixels          */
 #define RCV_F_TRAINING  128u  /* BN_FINALIZE: update running stats                                */
+#define RCV_F_SIDE_STREAM (1u << 16) /* rcv_run: enqueue this op on the handle's side stream (forked from / joined to the caller's
+                                      * stream inside the call): ops off the critical path, e.g. the filter gradients of backward */
 #define RCV_F_CONCAT    256u  /* COMBINE: out[..,0:C] = relu(t*s+h), out[..,C:2C] = f(r)  (v2 skip concat, model.py:507) */
 #define RCV_F_DBG_NOSTAGE (1u << 20) /* profiling ablation: skip the global->LDS input staging (results are garbage) */
 #define RCV_F_DBG_NOMFMA  (1u << 21) /* profiling ablation: skip the MFMA contraction (results are garbage)          */

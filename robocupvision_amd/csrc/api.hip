@@ -33,11 +33,20 @@ int rcv_create(int device, rcv_handle** out) {
   h->device = device;
   h->num_cus = prop.multiProcessorCount;
   h->max_lds = 160 * 1024;
+  h->side_stream = nullptr;
+  h->ev_join = nullptr;
+  h->ev_next = 0;
+  for (auto& e : h->ev_fork) e = nullptr;
   *out = h;
   return RCV_OK;
 }
 
 int rcv_destroy(rcv_handle* h) {
+  if (h && h->side_stream) {
+    (void)hipStreamDestroy(h->side_stream);
+    (void)hipEventDestroy(h->ev_join);
+    for (auto& e : h->ev_fork) (void)hipEventDestroy(e);
+  }
   delete h;
   return RCV_OK;
 }
@@ -72,15 +81,38 @@ int rcv_op_workspace(const rcv_handle* h, rcv_op* op, size_t* part_bytes) {
 int rcv_run(rcv_handle* h, const rcv_op* ops, int n, void* stream) {
   RCV_CHECK_ARG(h && (ops || n == 0) && n >= 0, "rcv_run: bad arguments");
   hipStream_t s = (hipStream_t)stream;
+  // Ops flagged RCV_F_SIDE_STREAM run on the handle's side stream: it is forked from `stream` in front of every run of such ops
+  // (event record on `stream`, wait on the side stream) and joined back before rcv_run returns, so the caller keeps seeing ONE
+  // stream-ordered call.  No host synchronisation; capturable (the side stream joins the capture through the events).
+  bool prev_side = false, side_used = false;
   for (int k = 0; k < n; ++k) {
-    const int rc = dispatch(h, &ops[k], s, nullptr);
+    const bool side = (ops[k].flags & RCV_F_SIDE_STREAM) != 0;
+    if (side && !h->side_stream) {
+      RCV_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+      RCV_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+      for (auto& e : h->ev_fork) RCV_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (side && !prev_side) {
+      hipEvent_t e = h->ev_fork[h->ev_next];
+      h->ev_next = (h->ev_next + 1) % 8;
+      RCV_HIP(hipEventRecord(e, s));
+      RCV_HIP(hipStreamWaitEvent(h->side_stream, e, 0));
+      side_used = true;
+    }
+    prev_side = side;
+    const int rc = dispatch(h, &ops[k], side ? h->side_stream : s, nullptr);
     if (rc) {
       char tmp[400];
       strncpy(tmp, g_err, sizeof(tmp) - 1);
       tmp[sizeof(tmp) - 1] = 0;
       rcv_set_error("op %d (kind %d): %s", k, ops[k].kind, tmp);
+      if (side_used) { (void)hipEventRecord(h->ev_join, h->side_stream); (void)hipStreamWaitEvent(s, h->ev_join, 0); }
       return rc;
     }
+  }
+  if (side_used) {
+    RCV_HIP(hipEventRecord(h->ev_join, h->side_stream));
+    RCV_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
   }
   return RCV_OK;
 }

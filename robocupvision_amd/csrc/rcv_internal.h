@@ -9,6 +9,12 @@ struct rcv_handle {
   int device;
   int num_cus;
   int max_lds;   // bytes of LDS one workgroup may use
+  // RCV_F_SIDE_STREAM: ops off the critical path (filter gradients) run on this stream, forked from / joined to the caller's
+  // stream with events inside rcv_run; created on first use
+  hipStream_t side_stream;
+  hipEvent_t ev_fork[8];
+  hipEvent_t ev_join;
+  int ev_next;
 };
 
 void rcv_set_error(const char* fmt, ...);
