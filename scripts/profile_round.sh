@@ -4,6 +4,9 @@ TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# per-kernel numbers are taken with the backward pass on ONE stream (RCV_NO_SIDE_STREAM): with the filter gradients overlapped on the
+# side stream a kernel's duration includes the time it shares the chip, which is not what bench.py's per-op HIP events report
+export RCV_NO_SIDE_STREAM=1
 CMD="python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/bench_stats.json 2> $OUT/stats.err
 echo "stats exit=$?"
