@@ -170,6 +170,14 @@ int rcv_op_workspace(const rcv_handle* h, rcv_op* op, size_t* part_bytes);
 /* Enqueue ops[0..n) in order on `stream`. */
 int rcv_run(rcv_handle* h, const rcv_op* ops, int n, void* stream);
 
+/* rcv_run with options.  RCV_RUN_NO_JOIN: leave the side stream (RCV_F_SIDE_STREAM ops) un-joined when the call returns; the caller
+ * joins it later with rcv_join_side (data-parallel training runs the backward list in slices and lets the communication stream,
+ * not the compute stream, wait for the filter gradients of a slice). */
+#define RCV_RUN_NO_JOIN 1u
+int rcv_run_ex(rcv_handle* h, const rcv_op* ops, int n, void* stream, uint32_t run_flags);
+/* Make `stream` wait for everything enqueued on the handle's side stream so far (no-op if none exists). */
+int rcv_join_side(rcv_handle* h, void* stream);
+
 /* Profiling aid (not for the training path: it creates HIP events and synchronises the stream):
  * runs ops[0..n) like rcv_run with a hipEvent pair around every op and writes the elapsed
  * milliseconds of op k to ms[k] (host memory). */

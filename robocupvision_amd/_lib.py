@@ -39,7 +39,7 @@ class RcvPackJob(C.Structure):
 
 EXPORTS = [
     "rcv_create", "rcv_destroy", "rcv_last_error", "rcv_version", "rcv_num_cus", "rcv_op_workspace", "rcv_run",
-    "rcv_run_timed", "rcv_op_kernel_label",
+    "rcv_run_timed", "rcv_op_kernel_label", "rcv_run_ex", "rcv_join_side",
     "rcv_conv3x3", "rcv_convT3x3s2", "rcv_wgrad3x3", "rcv_bn_finalize", "rcv_bn_backward", "rcv_maxpool2x2_fwd",
     "rcv_softmax_ce_argmax_fwd", "rcv_softmax_ce_bwd", "rcv_adam_l1_step", "rcv_confusion",
     "rcv_dice_fwd", "rcv_dice_bwd", "rcv_sgd_step",
@@ -73,6 +73,8 @@ def load():
         lib.rcv_num_cus.argtypes = [C.c_void_p]
         lib.rcv_op_workspace.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.POINTER(C.c_size_t)]
         lib.rcv_run.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_int, C.c_void_p]
+        lib.rcv_run_ex.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_int, C.c_void_p, C.c_uint32]
+        lib.rcv_join_side.argtypes = [C.c_void_p, C.c_void_p]
         lib.rcv_run_timed.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_int, C.c_void_p, C.POINTER(C.c_float)]
         lib.rcv_op_kernel_label.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_char_p, C.c_int]
         for name in ("rcv_conv3x3", "rcv_convT3x3s2", "rcv_wgrad3x3"):
@@ -97,6 +99,11 @@ def handle(device_index: int):
         h = out
         _handles[device_index] = h
     return h
+
+
+def join_side(h, stream_ptr: int):
+    """Make the stream wait for everything the handle's side stream holds so far."""
+    check(load().rcv_join_side(h, C.c_void_p(stream_ptr)), "rcv_join_side")
 
 
 def make_op(kind: int, flags: int = 0, **kw) -> RcvOp:
@@ -132,10 +139,11 @@ class OpList:
         if self.n:
             check(load().rcv_run(h, self.arr, self.n, C.c_void_p(stream_ptr)), "rcv_run")
 
-    def run_slice(self, h, stream_ptr: int, start: int, end: int):
+    def run_slice(self, h, stream_ptr: int, start: int, end: int, join: bool = True):
+        """Ops [start, end); join=False leaves the side stream un-joined (see join_side)."""
         if end > start:
             first = C.cast(C.byref(self.arr, start * C.sizeof(RcvOp)), C.POINTER(RcvOp))
-            check(load().rcv_run(h, first, end - start, C.c_void_p(stream_ptr)), "rcv_run")
+            check(load().rcv_run_ex(h, first, end - start, C.c_void_p(stream_ptr), 0 if join else 1), "rcv_run_ex")
 
     def run_timed(self, h, stream_ptr: int):
         """Profiling aid: per-op milliseconds (HIP events around every op; synchronises)."""

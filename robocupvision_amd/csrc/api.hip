@@ -78,7 +78,25 @@ int rcv_op_workspace(const rcv_handle* h, rcv_op* op, size_t* part_bytes) {
   return RCV_OK;
 }
 
-int rcv_run(rcv_handle* h, const rcv_op* ops, int n, void* stream) {
+static int run_ops(rcv_handle* h, const rcv_op* ops, int n, void* stream, bool join);
+
+int rcv_run(rcv_handle* h, const rcv_op* ops, int n, void* stream) { return run_ops(h, ops, n, stream, true); }
+
+int rcv_run_ex(rcv_handle* h, const rcv_op* ops, int n, void* stream, uint32_t run_flags) {
+  return run_ops(h, ops, n, stream, !(run_flags & RCV_RUN_NO_JOIN));
+}
+
+int rcv_join_side(rcv_handle* h, void* stream) {
+  RCV_CHECK_ARG(h, "rcv_join_side: NULL handle");
+  if (!h->side_stream) return RCV_OK;         // nothing was ever forked
+  RCV_HIP(hipEventRecord(h->ev_join, h->side_stream));
+  RCV_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0));
+  return RCV_OK;
+}
+
+}  // extern "C"
+
+static int run_ops(rcv_handle* h, const rcv_op* ops, int n, void* stream, bool join) {
   RCV_CHECK_ARG(h && (ops || n == 0) && n >= 0, "rcv_run: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   // Ops flagged RCV_F_SIDE_STREAM run on the handle's side stream: it is forked from `stream` in front of every run of such ops
@@ -110,12 +128,14 @@ int rcv_run(rcv_handle* h, const rcv_op* ops, int n, void* stream) {
       return rc;
     }
   }
-  if (side_used) {
+  if (side_used && join) {
     RCV_HIP(hipEventRecord(h->ev_join, h->side_stream));
     RCV_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
   }
   return RCV_OK;
 }
+
+extern "C" {
 
 int rcv_op_kernel_label(const rcv_handle* h, const rcv_op* op, char* buf, int size) {
   RCV_CHECK_ARG(h && op && buf && size > 0, "rcv_op_kernel_label: bad arguments");

@@ -728,16 +728,19 @@ class Engine:
         if self.grad_ready_cb is None or not plan.bwd_marks:
             plan.bwd.run(self.handle, stream)
             return plan
-        # bucketed: run the op list in slices and hand finished gradient ranges to the caller (all-reduce on a side stream)
+        # bucketed: run the op list in slices and hand finished gradient ranges to the caller (all-reduce on a side stream).  The
+        # slices do not join the filter-gradient stream back (that would stall the d(activation) chain at every bucket border): the
+        # callback makes ITS stream wait for it (join_side), the compute stream joins once at the end.
         done, hi = 0, self.flat.numel
         for (end, lo) in select_buckets(plan.bwd_marks, self.flat.numel, self.grad_buckets):
-            plan.bwd.run_slice(self.handle, stream, done, end)
+            plan.bwd.run_slice(self.handle, stream, done, end, join=False)
             done = end
             if lo < hi:
                 self.grad_ready_cb(lo, hi)
                 hi = lo
         if done < plan.bwd.n:
-            plan.bwd.run_slice(self.handle, stream, done, plan.bwd.n)
+            plan.bwd.run_slice(self.handle, stream, done, plan.bwd.n, join=False)
         if hi > 0:
             self.grad_ready_cb(0, hi)
+        L.join_side(self.handle, stream)
         return plan

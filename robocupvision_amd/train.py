@@ -55,6 +55,8 @@ class Trainer:
             self.world = dist.get_world_size()
             self.optimizer.grad_scale = 1.0 / self.world
             self.comm_stream = torch.cuda.Stream(device=dev) if overlap else None
+            if os.environ.get("RCV_GRAD_BUCKETS"):       # experiment knob: number of gradient buckets (default 3)
+                model._get_engine().grad_buckets = max(1, int(os.environ["RCV_GRAD_BUCKETS"]))
             # identical parameters on every rank before the first step
             for p in model.parameters():
                 dist.broadcast(p.data, 0)
@@ -63,12 +65,16 @@ class Trainer:
         """flat.grad[lo:hi] is final (called from inside backward, reverse layer order): sum it over the ranks on the
         side stream while the remaining backward kernels keep the compute stream busy."""
         import torch.distributed as dist
-        fl = self.model._get_engine().flat
+        eng = self.model._get_engine()
+        fl = eng.flat
         bucket = fl.grad[lo:hi]
+        cur = torch.cuda.current_stream(self.device)
         if self.comm_stream is None:
+            L.join_side(eng.handle, cur.cuda_stream)        # filter gradients are produced on the library's side stream
             dist.all_reduce(bucket)
             return
-        self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+        self.comm_stream.wait_stream(cur)
+        L.join_side(eng.handle, self.comm_stream.cuda_stream)
         with torch.cuda.stream(self.comm_stream):
             dist.all_reduce(bucket)
         self._pending = self.comm_stream
