@@ -124,7 +124,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
   const bool p_two = a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC;
   const bool g_two = a.g_mode == RCV_LOAD_GRAD_ENC || a.g_mode == RCV_LOAD_GRAD_DEC;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int UNR = (!SPEC && FOLD) ? 8 : 4;      // folded (<= 8 channel) tiles are HBM bound: more loads in flight
+  constexpr int UNR = (FOLD || (SPEC && WAVES_K != 2)) ? 8 : 4;     // folded (<= 8 channel) tiles are HBM bound: more loads in flight
   auto stage = [&](int tile, float* pl, float* gl) {
     int t = tile;
     const int tx_i = t % a.tiles_x;
@@ -244,6 +244,44 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
     }
   };
 
+  const bool do_stage = !(a.dbg & RCV_F_DBG_NOSTAGE), do_mfma = !(a.dbg & RCV_F_DBG_NOMFMA);
+  if (QP < QPMAX) {      // the channel columns no staging thread writes must read as zero
+    const int nfl = (SPEC ? 2 : 1) * bufsz;
+    for (int e = threadIdx.x; e < nfl; e += blockDim.x) smem[e] = 0.f;
+    __syncthreads();
+  }
+  // bias partial: sum over the threads that staged the same channel quad (fixed order); runs after the main loop
+  auto bias_partial = [&]() {
+    if (a.part_bias && ca_tile == 0) {
+      __syncthreads();
+      float4* sb = reinterpret_cast<float4*>(smem);
+      if (stager) sb[tid] = bsum;            // the staging threads summed the pointwise operand
+      __syncthreads();
+      if (stager && tid < QP) {
+        float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = tid; e < NT; e += QP) { const float4 v = sb[e]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
+        const int cb = cb0 + 4 * tid;
+        if (cb < a.CBP) *reinterpret_cast<float4*>(a.part_bias + (size_t)split * a.CBP + cb) = u;
+      }
+    }
+  };
+  if (SPEC && producer) {
+    // Producer waves: their whole program, BEFORE the accumulators exist (the 144 accumulator registers of the consumer role
+    // are then not live here, which is what lets 8 loads per thread stay in flight).  Barrier for barrier the same sequence as
+    // the consumer path below: 1 + one per tile + 2 per extra pixel slice + the bias partial's.
+    if (split < a.ntiles && do_stage) stage(split, smem, smem + a.pl_floats);
+    __syncthreads();
+    int it = 0;
+    for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
+      const int next = tile + a.nsplit;
+      if (next < a.ntiles && do_stage) { float* pn = smem + ((it + 1) & 1) * bufsz; stage(next, pn, pn + a.pl_floats); }
+      __syncthreads();
+    }
+    for (int kk = 1; kk < WAVES_K; ++kk) { __syncthreads(); __syncthreads(); }
+    bias_partial();
+    return;
+  }
+
   // ---------------- accumulators and lane offsets ----------------
   f32x4 acc[NACC][WM];
 #pragma unroll
@@ -288,25 +326,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
       }
     }
   };
-  const bool do_stage = !(a.dbg & RCV_F_DBG_NOSTAGE), do_mfma = !(a.dbg & RCV_F_DBG_NOMFMA);
-  if (QP < QPMAX) {      // the channel columns no staging thread writes must read as zero
-    const int nfl = (SPEC ? 2 : 1) * bufsz;
-    for (int e = threadIdx.x; e < nfl; e += blockDim.x) smem[e] = 0.f;
-    __syncthreads();
-  }
   if (SPEC) {
-    // producer waves stage tile i+1 into the other buffer while the consumer waves contract tile i: one barrier per tile
-    if (producer && split < a.ntiles && do_stage) stage(split, smem, smem + a.pl_floats);
+    // the producer waves (above) stage tile i+1 into the other buffer while these consumer waves contract tile i: one barrier per tile
     __syncthreads();
     int it = 0;
     for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
       float* pl = smem + (it & 1) * bufsz;
-      if (producer) {
-        const int next = tile + a.nsplit;
-        if (next < a.ntiles && do_stage) { float* pn = smem + ((it + 1) & 1) * bufsz; stage(next, pn, pn + a.pl_floats); }
-      } else if (do_mfma) {
-        contract(pl, pl + a.pl_floats);
-      }
+      if (do_mfma) contract(pl, pl + a.pl_floats);
       __syncthreads();
     }
   } else {
@@ -365,19 +391,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
         }
     }
   }
-  // ---- bias partial: sum over the threads that staged the same channel quad (fixed order) ----
-  if (a.part_bias && ca_tile == 0) {
-    __syncthreads();
-    float4* sb = reinterpret_cast<float4*>(smem);
-    if (stager) sb[tid] = bsum;            // the staging threads summed the pointwise operand
-    __syncthreads();
-    if (stager && tid < QP) {
-      float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int e = tid; e < NT; e += QP) { const float4 v = sb[e]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
-      const int cb = cb0 + 4 * tid;
-      if (cb < a.CBP) *reinterpret_cast<float4*>(a.part_bias + (size_t)split * a.CBP + cb) = u;
-    }
-  }
+  bias_partial();
 }
 
 // dW[cb][ca][tap] = sum_split part[split][tap][cb][ca];  db[cb] = sum_split part_bias[split][cb]
