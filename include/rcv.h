@@ -114,6 +114,9 @@ enum {
 #define RCV_F_TRANSPOSED_SRC 32u /* PACK / WGRAD_REDUCE: parameter is [Cin][Cout][3][3] (convT)  */
 #define RCV_F_ARGMAX    64u   /* CE_FWD: also write argmax mask and count correct pixels          */
 #define RCV_F_TRAINING  128u  /* BN_FINALIZE: update running stats                                */
+#define RCV_F_FUSED_UP   512u  /* CLS_FWD / CLS_BWD: the input is the decoder output relu(t*c0+c1) + f(r), formed on the fly from t (p[IN] resp.
+                               * p[EPI_AUX]), its constants (p[IN_C] resp. p[EPI_C]), the skip tensor p[X3], its constants p[X4], i[AUX0] = its
+                               * load mode -- RCV_OP_COMBINE is then not needed for this value                                             */
 #define RCV_F_SIDE_STREAM (1u << 16) /* rcv_run: enqueue this op on the handle's side stream (forked from / joined to the caller's
                                       * stream inside the call): ops off the critical path, e.g. the filter gradients of backward */
 #define RCV_F_CONCAT    256u  /* COMBINE: out[..,0:C] = relu(t*s+h), out[..,C:2C] = f(r)  (v2 skip concat, model.py:507) */

@@ -156,15 +156,15 @@ int rcv_run_timed(rcv_handle* h, const rcv_op* ops, int n, void* stream, float* 
     if (hipEventCreate(&ev[k]) != hipSuccess) { rcv_set_error("rcv_run_timed: hipEventCreate failed"); delete[] ev; return RCV_E_HIP; }
   }
   int rc = RCV_OK;
-  hipEventRecord(ev[0], s);
+  (void)hipEventRecord(ev[0], s);
   for (int k = 0; k < n && rc == RCV_OK; ++k) {
     rc = dispatch(h, &ops[k], s, nullptr);
-    hipEventRecord(ev[k + 1], s);
+    (void)hipEventRecord(ev[k + 1], s);
   }
   if (hipStreamSynchronize(s) != hipSuccess && rc == RCV_OK) { rcv_set_error("rcv_run_timed: stream sync failed"); rc = RCV_E_HIP; }
   if (rc == RCV_OK)
-    for (int k = 0; k < n; ++k) hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]);
-  for (int k = 0; k <= n; ++k) hipEventDestroy(ev[k]);
+    for (int k = 0; k < n; ++k) (void)hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]);
+  for (int k = 0; k <= n; ++k) (void)hipEventDestroy(ev[k]);
   delete[] ev;
   return rc;
 }

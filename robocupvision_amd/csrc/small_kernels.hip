@@ -190,9 +190,34 @@ __global__ void concat_kernel(const float* __restrict__ t, const float* __restri
 // 1x1 classifier (model.py:411): NHWC [.,CIN] -> NCHW logits [N][COUT][H][W]
 // ------------------------------------------------------------------------------------------
 #define CLS_MAX_OUT 8
-template <int CIN>
+// FUSED: the classifier input up = relu(t*c0+c1) + f(r) (decoder block output + skip, model.py:509) is formed here from the
+// block's raw tensors instead of being materialised by RCV_OP_COMBINE (saves one tensor write and one read at full resolution).
+template <int CIN, bool FUSED>
+__device__ __forceinline__ void cls_load_up(float (&v)[CIN], const float* __restrict__ x, const float* __restrict__ tc,
+                                            const float* __restrict__ r, const float* __restrict__ rc, int mode2, size_t p) {
+#pragma unroll
+  for (int q = 0; q < CIN / 4; ++q) {
+    float4 a = sld4(x + p * CIN + 4 * q);
+    if (FUSED) {
+      const float4 s = sld4(tc + 4 * q), h = sld4(tc + CIN + 4 * q);
+      a.x = fmaxf(fmaf(a.x, s.x, h.x), 0.f); a.y = fmaxf(fmaf(a.y, s.y, h.y), 0.f);
+      a.z = fmaxf(fmaf(a.z, s.z, h.z), 0.f); a.w = fmaxf(fmaf(a.w, s.w, h.w), 0.f);
+      float4 b = sld4(r + p * CIN + 4 * q);
+      if (mode2 != RCV_LOAD_PLAIN) {
+        const float4 s2 = sld4(rc + 4 * q), h2 = sld4(rc + CIN + 4 * q);
+        b.x = fmaf(b.x, s2.x, h2.x); b.y = fmaf(b.y, s2.y, h2.y); b.z = fmaf(b.z, s2.z, h2.z); b.w = fmaf(b.w, s2.w, h2.w);
+        if (mode2 == RCV_LOAD_AFFINE_RELU) { b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f); }
+      }
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+  }
+}
+
+template <int CIN, bool FUSED>
 __global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                               float* __restrict__ out, int N, int HW, int COUT) {
+                               float* __restrict__ out, int N, int HW, int COUT, const float* __restrict__ tc,
+                               const float* __restrict__ r, const float* __restrict__ rc, int mode2) {
   __shared__ float ws[CLS_MAX_OUT * CIN + CLS_MAX_OUT];
   for (int e = threadIdx.x; e < COUT * CIN; e += blockDim.x) ws[e] = w[e];
   for (int e = threadIdx.x; e < COUT; e += blockDim.x) ws[CLS_MAX_OUT * CIN + e] = bias ? bias[e] : 0.f;
@@ -200,11 +225,7 @@ __global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restr
   const size_t total = (size_t)N * HW;
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
     float v[CIN];
-#pragma unroll
-    for (int q = 0; q < CIN / 4; ++q) {
-      const float4 a = sld4(x + p * CIN + 4 * q);
-      v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
-    }
+    cls_load_up<CIN, FUSED>(v, x, tc, r, rc, mode2, p);
     const size_t n = p / HW, hw = p % HW;
 #pragma unroll
     for (int c = 0; c < CLS_MAX_OUT; ++c) {
@@ -220,10 +241,11 @@ __global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restr
 
 // classifier backward: d_up[p][k] = sum_c dl[c][p] W[c][k];  dW[c][k] = sum_p dl[c][p] up[p][k];
 // db[c] = sum_p dl[c][p];  optional decoder BN-backward statistics of d_up against t.
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool FUSED>
 __global__ __launch_bounds__(256, 2) void cls_bwd_kernel(const float* __restrict__ up, const float* __restrict__ dl, const float* __restrict__ w,
                                float* __restrict__ dup, const float* __restrict__ t, const float* __restrict__ tc,
-                               float* __restrict__ stat_part, float* __restrict__ w_part, int N, int HW, int stats) {
+                               float* __restrict__ stat_part, float* __restrict__ w_part, int N, int HW, int stats,
+                               const float* __restrict__ r, const float* __restrict__ rc, int mode2) {
   __shared__ float ws[COUT * CIN];
   __shared__ float red[4][COUT * CIN + COUT + 2 * CIN];
   for (int e = threadIdx.x; e < COUT * CIN; e += blockDim.x) ws[e] = w[e];
@@ -241,11 +263,7 @@ __global__ __launch_bounds__(256, 2) void cls_bwd_kernel(const float* __restrict
     float g[COUT], u[CIN], d[CIN];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) g[c] = dl[(n * COUT + c) * HW + hw];
-#pragma unroll
-    for (int q = 0; q < CIN / 4; ++q) {
-      const float4 a = sld4(up + p * CIN + 4 * q);
-      u[4 * q] = a.x; u[4 * q + 1] = a.y; u[4 * q + 2] = a.z; u[4 * q + 3] = a.w;
-    }
+    cls_load_up<CIN, FUSED>(u, FUSED ? t : up, tc, r, rc, mode2, p);      // FUSED: up is re-formed from t and the skip tensor
 #pragma unroll
     for (int k = 0; k < CIN; ++k) {
       float acc = 0.f;
@@ -885,10 +903,17 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       RCV_CHECK_ARG((Cin == 8 || Cin == 16) && Cout >= 1 && Cout <= CLS_MAX_OUT, "classifier: Cin=%d Cout=%d unsupported", Cin, Cout);
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_W] && op->p[RCV_P_OUT], "classifier: null operand");
       const int g = stream_grid(h, (size_t)N * H * W, 256);
-      if (Cin == 8)
-        hipLaunchKernelGGL(cls_fwd_kernel<8>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout);
+      const bool fused = (op->flags & RCV_F_FUSED_UP) != 0;
+      const float* tc = (const float*)op->p[RCV_P_IN_C]; const float* r = (const float*)op->p[RCV_P_X3]; const float* rc = (const float*)op->p[RCV_P_X4];
+      const int mode2 = op->i[RCV_I_AUX0];
+      if (fused) {
+        RCV_CHECK_ARG(Cin == 8 && tc && r && (mode2 == RCV_LOAD_PLAIN || rc), "classifier (fused decoder output): operands missing");
+        RCV_CHECK_ARG(mode2 == RCV_LOAD_PLAIN || mode2 == RCV_LOAD_AFFINE || mode2 == RCV_LOAD_AFFINE_RELU, "classifier: skip load mode %d", mode2);
+        hipLaunchKernelGGL((cls_fwd_kernel<8, true>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2);
+      } else if (Cin == 8)
+        hipLaunchKernelGGL((cls_fwd_kernel<8, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2);
       else
-        hipLaunchKernelGGL(cls_fwd_kernel<16>, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout);
+        hipLaunchKernelGGL((cls_fwd_kernel<16, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2);
       break;
     }
     case RCV_OP_CLS_BWD: {
@@ -901,16 +926,26 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
         return RCV_OK;
       }
       RCV_CHECK_ARG(Cin == 8 && Cout == 5, "classifier backward: only 8 -> 5 is built (got %d -> %d)", Cin, Cout);
-      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_W] && op->p[RCV_P_OUT] && op->p[RCV_P_PART] && op->p[RCV_P_X1],
+      const bool fused = (op->flags & RCV_F_FUSED_UP) != 0;
+      RCV_CHECK_ARG((fused || op->p[RCV_P_IN]) && op->p[RCV_P_IN2] && op->p[RCV_P_W] && op->p[RCV_P_OUT] && op->p[RCV_P_PART] && op->p[RCV_P_X1],
                     "classifier backward: null operand");
       RCV_CHECK_ARG(op->i[RCV_I_NPART] == g, "classifier backward: workspace rows %d != %d", op->i[RCV_I_NPART], g);
       const int stats = op->i[RCV_I_STATS];
       RCV_CHECK_ARG(stats == RCV_STATS_NONE || (op->p[RCV_P_EPI_AUX] && op->p[RCV_P_EPI_C]), "classifier backward: stats operands missing");
       float* stat_part = (float*)op->p[RCV_P_PART];
       float* w_part = stat_part + (size_t)g * 2 * Cin;
-      hipLaunchKernelGGL((cls_bwd_kernel<8, 5>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
-                         (const float*)op->p[RCV_P_W], (float*)op->p[RCV_P_OUT], (const float*)op->p[RCV_P_EPI_AUX],
-                         (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats);
+      const float* r = (const float*)op->p[RCV_P_X3]; const float* rc = (const float*)op->p[RCV_P_X4];
+      const int mode2 = op->i[RCV_I_AUX0];
+      if (fused) {
+        RCV_CHECK_ARG(stats == RCV_STATS_BWD_DEC && r && (mode2 == RCV_LOAD_PLAIN || rc), "classifier backward (fused decoder output): operands missing");
+        hipLaunchKernelGGL((cls_bwd_kernel<8, 5, true>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
+                           (const float*)op->p[RCV_P_W], (float*)op->p[RCV_P_OUT], (const float*)op->p[RCV_P_EPI_AUX],
+                           (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats, r, rc, mode2);
+      } else {
+        hipLaunchKernelGGL((cls_bwd_kernel<8, 5, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
+                           (const float*)op->p[RCV_P_W], (float*)op->p[RCV_P_OUT], (const float*)op->p[RCV_P_EPI_AUX],
+                           (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats, r, rc, mode2);
+      }
       RCV_HIP(hipGetLastError());
       // dW -> p[X1] ([Cout][Cin]), db -> p[X2]
       hipLaunchKernelGGL(rows_reduce_kernel, dim3((int)wrow), dim3(256), 0, s, w_part, g, (int)wrow, (float*)op->p[RCV_P_X1], Cout * Cin,

@@ -28,6 +28,7 @@ from . import _lib as L
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 SIDE_STREAM_WGRAD = not os.environ.get("RCV_NO_SIDE_STREAM")
+FUSE_UP_INTO_CLS = not os.environ.get("RCV_NO_FUSED_UP")
 CLS3_PAD = 8                    # class channels of the 3x3 classifier (v2) are padded to this many NHWC channels
 MERGED_TCONV_MAX_COUT = 16      # transposed convs with at most this many output channels use the merged-parity kernel
 
@@ -79,7 +80,7 @@ class Value:
 
     @property
     def load_mode(self) -> int:
-        return {"plain": L.LOAD_PLAIN, "affine": L.LOAD_AFFINE, "affine_relu": L.LOAD_AFFINE_RELU, "nchw": L.LOAD_NCHW}[self.kind]
+        return {"plain": L.LOAD_PLAIN, "affine": L.LOAD_AFFINE, "affine_relu": L.LOAD_AFFINE_RELU, "nchw": L.LOAD_NCHW}[self.kind]      # 'fused_up' values are read by the classifier ops only
 
 
 class _Node:
@@ -283,6 +284,11 @@ class Engine:
                                      p_x2=bn.running_mean.data_ptr(), p_x3=bn.running_var.data_ptr()))
                 fwd.append(conv_op)
 
+        def only_consumer_is_cls1x1(idx: int) -> bool:
+            users = [nd for nd in nodes if any(nd.d.get(k) == ("node", idx) for k in ("src", "skip", "add"))]
+            return (len(users) == 1 and users[0].op == "cls" and tuple(users[0].d["weight"].shape[2:]) == (1, 1)
+                    and users[0].d["weight"].shape[0] == 5)
+
         # =============================== forward ===============================
         for node in nodes:
             d = node.d
@@ -343,6 +349,11 @@ class Engine:
                         raise L.RcvError("up node %d: skip tensor %s does not match output %s" %
                                          (node.idx, (skip.C, skip.H, skip.W), (Cout, Ho, Wo)))
                     concat = bool(d.get("concat"))      # v2: torch.cat([layer(up), skip], 1) instead of the add (model.py:507)
+                    if not concat and FUSE_UP_INTO_CLS and Cout == 8 and skip.input_index is None and only_consumer_is_cls1x1(node.idx):
+                        # the 1x1 classifier forms relu(bn(t)) + bn(skip) itself (RCV_F_FUSED_UP): no RCV_OP_COMBINE, `up` never exists
+                        node.out = Value("fused_up", None, Cout, Ho, Wo, node.t["consts"], node)
+                        node.out.fused = (t, skip)
+                        continue
                     Cup = 2 * Cout if concat else Cout
                     up = self._alloc(plan, N, Ho, Wo, Cup)
                     cop = L.make_op(L.OP_COMBINE, L.F_CONCAT if concat else 0, n=N, h=Ho, w=Wo, cout=Cout, inmode2=skip.load_mode,
@@ -356,12 +367,17 @@ class Engine:
                 src = ref(d["src"])
                 w, b = d["weight"], d.get("bias")
                 Cout, Cin = w.shape[0], w.shape[1]
-                if src.kind != "plain":
+                if src.kind not in ("plain", "fused_up"):
                     raise L.RcvError("classifier input must be a materialised tensor")
                 if Cin != src.C:
                     raise L.RcvError("classifier: input has %d channels, weight expects %d" % (src.C, Cin))
                 logits = self._alloc(plan, N, Cout, src.H, src.W)
-                if tuple(w.shape[2:]) == (1, 1):
+                if tuple(w.shape[2:]) == (1, 1) and src.kind == "fused_up":
+                    tt, skip = src.fused
+                    fwd.append(L.make_op(L.OP_CLS_FWD, L.F_FUSED_UP, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, aux0=skip.load_mode,
+                                         p_in=tt.data_ptr(), p_in_c=src.consts.data_ptr(), p_x3=skip.buf.data_ptr(), p_x4=_ptr(skip.consts),
+                                         p_w=w.data_ptr(), p_bias=_ptr(b), p_out=logits.data_ptr()))
+                elif tuple(w.shape[2:]) == (1, 1):
                     op = L.make_op(L.OP_CLS_FWD, 0, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, p_w=w.data_ptr(), p_bias=_ptr(b),
                                    p_out=logits.data_ptr())
                     op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
@@ -490,6 +506,12 @@ class Engine:
                         continue
                     op = L.make_op(L.OP_CLS_BWD, 0, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, p_in=src.buf.data_ptr() if src.buf is not None else 0,
                                    p_w=w.data_ptr(), p_x1=fl.grad_ptr(w), p_x2=(fl.grad_ptr(b) if b is not None else 0))
+                    if src.kind == "fused_up":
+                        _tt, skip = src.fused
+                        op.flags |= L.F_FUSED_UP
+                        op.i[L.RCV_I_AUX0] = skip.load_mode
+                        op.p[L.RCV_P_X3] = skip.buf.data_ptr()
+                        op.p[L.RCV_P_X4] = _ptr(skip.consts) or None
                     if src.input_index is not None:
                         plan.input_slots[src.input_index].append((True, len(bwd), L.RCV_P_IN))
                     plan.dlogits_slots.append((len(bwd), L.RCV_P_IN2))
