@@ -198,6 +198,21 @@ def test_determinism_bitwise():
         assert torch.equal(outs[0]["grads"][k], outs[1]["grads"][k]), k
 
 
+def test_scheduling_variants_are_bitwise_identical(monkeypatch):
+    """The second stream for the filter gradients and the classifier that forms the last decoder output itself change WHEN / WHERE
+    values are computed, not the arithmetic: logits and every gradient are bit-identical with either switched off."""
+    import robocupvision_amd.engine as E
+    x, t = O.synthetic_batch(2, 48, 64)
+    ref = hip_step(build(dict(noScale=True)).to(DEV), x.to(DEV), t.to(DEV), do_step=False)
+    for name in ("SIDE_STREAM_WGRAD", "FUSE_UP_INTO_CLS"):
+        monkeypatch.setattr(E, name, False)
+        out = hip_step(build(dict(noScale=True)).to(DEV), x.to(DEV), t.to(DEV), do_step=False)
+        monkeypatch.setattr(E, name, True)
+        assert torch.equal(out["pred"], ref["pred"]), name
+        for k in ref["grads"]:
+            assert torch.equal(out["grads"][k], ref["grads"][k]), (name, k)
+
+
 def test_grad_accumulation_semantics():
     """Two backward passes without zero_grad accumulate (param.grad aliases the engine buffer otherwise)."""
     x, t = O.synthetic_batch(1, 16, 24)
