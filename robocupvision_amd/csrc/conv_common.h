@@ -90,12 +90,18 @@ struct ConvPlan {
   int narrow;            // 1: convs_mfma.hip (persistent, filter resident in LDS)
   int dma;               // 1: conv_dma_kernel (filter chunks by LDS-DMA, double buffered)
   int WM, WN, XMAX;      // narrow kernel template selection
+  int first;             // 1: conv_first.hip (3 -> 8 channel first layer on the vector ALU)
 };
 
 static inline void tile_halo(int kind, int R, int Wt, int s, int d, int* IH, int* IW) {
   if (kind == KIND_GATHER) { *IH = (R - 1) * s + 2 * d + 1; *IW = (Wt - 1) * s + 2 * d + 1; }
   else { *IH = R + 1; *IW = Wt + 1; }
 }
+
+// first-layer kernel (conv_first.hip)
+bool conv_first_supported(const rcv_op* op, int kind);
+int conv_first_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl);
+int conv_first_launch(const ConvPlan& pl, const ConvArgs& a, hipStream_t s);
 
 // narrow-layer kernel (convs_mfma.hip)
 bool convs_supported(const rcv_handle* h, const rcv_op* op, int kind, int CinP, int CoutV);

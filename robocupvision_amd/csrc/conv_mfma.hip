@@ -639,6 +639,8 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   const int CinP = round_up(Cin, 4);
   pl->narrow = 0;
   pl->dma = 0;
+  pl->first = 0;
+  if (conv_first_supported(op, pl->kind)) return conv_first_plan(h, op, pl);
   if (convs_supported(h, op, pl->kind, CinP, pl->kind == KIND_TMERGED ? 4 * Cout : Cout)) return convs_make_plan(h, op, pl->kind, pl);
   pl->CK = (CinP % 8 == 0) ? 8 : 4;
   const int Q = pl->CK / 4;
@@ -718,10 +720,12 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   if (rc) return rc;
   const int Cout = op->i[RCV_I_COUT];
   const int n_pix_tiles = op->i[RCV_I_N] * pl.tiles_x * pl.tiles_y;
-  const int n_part = pl.narrow ? pl.grid : n_pix_tiles * pl.n_phases;
+  const int n_part = (pl.narrow || pl.first) ? pl.grid : n_pix_tiles * pl.n_phases;
   if (query) {
     static const char* kn[] = {"conv", "tconv", "tconvm"};
-    if (pl.narrow) {
+    if (pl.first) {
+      snprintf(query->label, sizeof(query->label), "conv_first<%d>", op->i[RCV_I_DIL]);
+    } else if (pl.narrow) {
       snprintf(query->label, sizeof(query->label), "%ss_mfma<%d,%d,%d>", kn[pl.kind], pl.WM, pl.WN, pl.CK);
     } else {
       const TileCfg& tc = kTiles[pl.tile];
@@ -763,6 +767,7 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   RCV_CHECK_ARG(a.stats == RCV_STATS_NONE || op->i[RCV_I_NPART] == n_part, "conv: workspace rows %d != %d", op->i[RCV_I_NPART], n_part);
   RCV_CHECK_ARG(!(a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC) || a.epi_aux, "conv: backward statistics need epi_aux");
   RCV_CHECK_ARG(!(a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC) || a.epi_c, "conv: backward statistics need epi_c (scale, shift, mean)");
+  if (pl.first) return conv_first_launch(pl, a, s);
   if (pl.narrow) return convs_launch(pl, a, a.in_mode == RCV_LOAD_GRAD_ENC || a.in_mode == RCV_LOAD_GRAD_DEC, s);
   const dim3 grid(pl.grid);
   if (pl.dma) {

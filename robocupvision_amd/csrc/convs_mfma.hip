@@ -324,7 +324,7 @@ int convs_make_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* p
   const int Ho = op->i[RCV_I_HO], Wo = op->i[RCV_I_WO];
   const int s = op->i[RCV_I_STRIDE], d = op->i[RCV_I_DIL];
   const int CinP = round_up(Cin, 4);
-  pl->kind = kind; pl->narrow = 1; pl->dma = 0;
+  pl->kind = kind; pl->narrow = 1; pl->dma = 0; pl->first = 0;
   pl->CK = CinP;
   pl->CoutV = kind == KIND_TMERGED ? 4 * Cout : Cout;
   pl->CoutP = round_up(pl->CoutV, 16);
