@@ -551,23 +551,23 @@ static int launch_dma_tile(int tile, const ConvArgs& a, dim3 grid, size_t lds, h
 }
 
 struct TileCfg {
-  int WM, WN, WAVES_M, WAVES_N, XMAX;
+  int WM, WN, WAVES_M, WAVES_N;
   int cot() const { return WM * WAVES_M * 16; }
   int pix() const { return WN * WAVES_N * 16; }
   int nt() const { return WAVES_M * WAVES_N * 64; }
 };
 static const TileCfg kTiles[] = {
-    {2, 5, 4, 1, 4},  // 0: COT 128, PIX  80
-    {2, 5, 2, 2, 6},  // 1: COT  64, PIX 160
-    {2, 5, 1, 4, 8},  // 2: COT  32, PIX 320
-    {1, 5, 1, 4, 8},  // 3: COT  16, PIX 320
-    {1, 5, 4, 1, 4},  // 4: COT  64, PIX  80
-    {1, 5, 2, 2, 6},  // 5: COT  32, PIX 160
-    {1, 5, 1, 2, 8},  // 6: COT  16, PIX 160 (128 threads)
+    {2, 5, 4, 1},  // 0: COT 128, PIX  80
+    {2, 5, 2, 2},  // 1: COT  64, PIX 160
+    {2, 5, 1, 4},  // 2: COT  32, PIX 320
+    {1, 5, 1, 4},  // 3: COT  16, PIX 320
+    {1, 5, 4, 1},  // 4: COT  64, PIX  80
+    {1, 5, 2, 2},  // 5: COT  32, PIX 160
+    {1, 5, 1, 2},  // 6: COT  16, PIX 160 (128 threads)
 };
 static const int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, int KIND, int XMAX>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, int KIND>
 static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   auto kern = conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, CK, KIND>;
   static size_t configured = 0;
@@ -583,13 +583,13 @@ static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) 
 template <int CK, int KIND>
 static int launch_tile(int tile, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
   switch (tile) {
-    case 0: return launch_inst<2, 5, 4, 1, CK, KIND, 4>(a, grid, lds, s);
-    case 1: return launch_inst<2, 5, 2, 2, CK, KIND, 6>(a, grid, lds, s);
-    case 2: return launch_inst<2, 5, 1, 4, CK, KIND, 8>(a, grid, lds, s);
-    case 3: return launch_inst<1, 5, 1, 4, CK, KIND, 8>(a, grid, lds, s);
-    case 4: return launch_inst<1, 5, 4, 1, CK, KIND, 4>(a, grid, lds, s);
-    case 5: return launch_inst<1, 5, 2, 2, CK, KIND, 6>(a, grid, lds, s);
-    default: return launch_inst<1, 5, 1, 2, CK, KIND, 8>(a, grid, lds, s);
+    case 0: return launch_inst<2, 5, 4, 1, CK, KIND>(a, grid, lds, s);
+    case 1: return launch_inst<2, 5, 2, 2, CK, KIND>(a, grid, lds, s);
+    case 2: return launch_inst<2, 5, 1, 4, CK, KIND>(a, grid, lds, s);
+    case 3: return launch_inst<1, 5, 1, 4, CK, KIND>(a, grid, lds, s);
+    case 4: return launch_inst<1, 5, 4, 1, CK, KIND>(a, grid, lds, s);
+    case 5: return launch_inst<1, 5, 2, 2, CK, KIND>(a, grid, lds, s);
+    default: return launch_inst<1, 5, 1, 2, CK, KIND>(a, grid, lds, s);
   }
 }
 
