@@ -514,7 +514,9 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   if (fold) pl->SG = 4 * QG + 1;
   else pl->SG = s == 1 ? (wt.cat() % 32 == 0 ? wt.cat() + 16 : wt.cat()) : wt.cat() + 8;
   // pixel tile: widest row segment, then as many rows as the prefetch registers and the LDS budget allow
-  const size_t budget = (wt.SPEC ? 78 : 80) * 1024 / sizeof(float);   // SPEC: per buffer (two buffers, one workgroup per CU); else two workgroups per CU
+  int per_cu = wt.SPEC ? 1 : 2;                     // SPEC: 512 threads, two LDS buffers => one workgroup per CU
+  if (const char* ev = getenv("RCV_WGRAD_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4 && !wt.SPEC) per_cu = o; }
+  const size_t budget = (wt.SPEC ? 78 : 160 / per_cu) * 1024 / sizeof(float);   // SPEC: per buffer
   int bestR = 0, bestWt = 0;
   for (int nx = 1; nx <= Wp && bestR == 0; ++nx) {
     const int Wt = ceil_div(Wp, nx), Wt4 = round_up(Wt, 4);
@@ -544,8 +546,6 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   RCV_CHECK_ARG(pl->lds <= (size_t)h->max_lds, "wgrad: tile needs %zu B of LDS (limit %d)", pl->lds, h->max_lds);
   const int ctiles = ceil_div(pl->CBP, wt.cbt()) * (fold ? 1 : ceil_div(pl->CAP, wt.cat()));
   const int ntiles = N * pl->tiles_x * pl->tiles_y;
-  int per_cu = wt.SPEC ? 1 : 2;                     // SPEC: 512 threads with > 128 registers => one workgroup per CU
-  if (const char* ev = getenv("RCV_WGRAD_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4) per_cu = o; }
   int nsplit = (per_cu * h->num_cus) / ctiles;
   if (nsplit < 1) nsplit = 1;
   if (nsplit > ntiles) nsplit = ntiles;
