@@ -121,6 +121,7 @@ enum {
                                       * stream inside the call): ops off the critical path, e.g. the filter gradients of backward */
 #define RCV_F_CONCAT    256u  /* COMBINE: out[..,0:C] = relu(t*s+h), out[..,C:2C] = f(r)  (v2 skip concat, model.py:507) */
 #define RCV_F_DBG_NOSTAGE (1u << 20) /* profiling ablation: skip the global->LDS input staging (results are garbage) */
+#define RCV_F_DBG_NOSKIP  (1u << 22) /* profiling ablation: merged transposed conv without skipping the structurally zero filter blocks */
 #define RCV_F_DBG_NOMFMA  (1u << 21) /* profiling ablation: skip the MFMA contraction (results are garbage)          */
 
 /* integer slots */

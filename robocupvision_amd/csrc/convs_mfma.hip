@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
     for (int r = 0; r < 4; ++r) { s1[m][r] = 0.f; s2[m][r] = 0.f; }
 
   const int IS = KIND == KIND_GATHER ? a.stride : 1;
+  const bool skip16 = KIND == KIND_TMERGED && WM == 4 && a.Cout == 16 && !(a.flags & RCV_F_DBG_NOSKIP);
+  const bool skip8 = KIND == KIND_TMERGED && WM == 2 && a.Cout == 8 && !(a.flags & RCV_F_DBG_NOSKIP);
   const int aoff = l4 * WS + l15;
   int tile = xcd_remap(blockIdx.x, gridDim.x);     // neighbouring tiles (shared halo rows) stay on one XCD
   if (tile < a.total_tiles) prefetch(tile);
@@ -184,10 +186,15 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int b = 0; b < WN; ++b) bv[b] = xj[pixoff[b] + kk * 4];
 #pragma unroll
-        for (int m = 0; m < WM; ++m)
+        for (int m = 0; m < WM; ++m) {
+          // merged transposed conv: the filter block of output parity (py,px) is structurally zero for the window taps with
+          // dy > py or dx > px (7 of the 16 (parity, tap) pairs).  Where a 16-channel block holds whole parities the MFMAs on
+          // those blocks are skipped: Cout = 16 -> block m is parity m; Cout = 8 -> block m holds both px of py = m.
+          if (KIND == KIND_TMERGED && ((skip16 && (jy > (m >> 1) || jx > (m & 1))) || (skip8 && jy > m))) continue;
 #pragma unroll
           for (int b = 0; b < WN; ++b)
             acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[m][b], 0, 0, 0);
+        }
       }
     }
 
