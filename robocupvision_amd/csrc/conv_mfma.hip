@@ -387,8 +387,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   auto dma_w = [&](int buf, int c0) {
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
-      const int e0 = (u * (NT / 64) + wave) * 64;           // first piece of this wave-instruction (wave uniform)
-      if (e0 < wtotal) {
+      int e0 = (u * (NT / 64) + wave) * 64;                 // first piece of this wave-instruction (wave uniform)
+      if (e0 >= wtotal) e0 = wtotal - 64;                   // every wave issues exactly WU instructions (a duplicate piece rewrites the
+      {                                                     // same bytes): the counted s_waitcnt of the pipelined loop relies on it
         const int e = e0 + lane;
         const int row = e / C4, c4 = e % C4;
         const int j = row / CK, ck = row % CK;
@@ -413,18 +414,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
 #pragma unroll
     for (int u = 0; u < XMAX; ++u) {
       const int pix = tid + u * NT;
-      px[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (TWO) pa[TWO ? u : 0] = px[u];
-      if (pix < npix) {
-        const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
-        const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
-        if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
-          okmask |= 1u << u;
-          const size_t off = ((size_t)(ti.n * a.H + gy) * a.W + gx) * a.Cin + c0;
-          px[u] = ld4(a.in + off);
-          if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
-        }
-      }
+      const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
+      const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
+      // branch-free (an invalid slot reads element c0 of pixel 0 and is masked in write_x): a fixed number of load instructions per
+      // wave keeps the compiler's and our own counted waits exact
+      const bool ok = pix < npix && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      okmask |= (ok ? 1u : 0u) << u;
+      const size_t off = (ok ? ((size_t)(ti.n * a.H + gy) * a.W + gx) * a.Cin : 0) + c0;
+      px[u] = ld4(a.in + off);
+      if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
     }
   };
   auto write_x = [&](int buf, int c0) {
@@ -471,18 +469,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
     for (int b = 0; b < WN; ++b) acc[m][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bool dbg_nostage = a.flags & RCV_F_DBG_NOSTAGE, dbg_nomfma = a.flags & RCV_F_DBG_NOMFMA;
-  if (!dbg_nostage) { dma_w(0, 0); load_x(0); }
   const int nchunks = a.CinP / CK;
-  for (int i = 0; i < nchunks; ++i) {
-    const int buf = i & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA pieces and input loads have landed
-    if (!dbg_nostage) write_x(buf, i * CK);
-    __syncthreads();          // everyone's pieces landed and tile written; everyone finished contracting chunk i-1
-    if (dbg_nomfma) { if (i + 1 < nchunks && !dbg_nostage) { dma_w(buf ^ 1, (i + 1) * CK); load_x((i + 1) * CK); } continue; }
-    if (i + 1 < nchunks && !dbg_nostage) {
-      dma_w(buf ^ 1, (i + 1) * CK);                       // in flight during the contraction below
-      load_x((i + 1) * CK);
-    }
+  // Pipeline over the 4-channel chunks.  F(c) = filter slab of chunk c (LDS-DMA into wl[c&1]); X(c) = input chunk (registers, then
+  // transformed into xl[c&1]).  In iteration i the MFMAs of chunk i run in two halves; between them X(i+1), loaded one iteration
+  // earlier, is written to the other input buffer and X(i+2) is requested, so neither the load latency nor the transform sits between
+  // two contractions; F(i+1) is requested right after the barrier that retires buffer (i+1)&1.  One barrier per chunk.
+  constexpr int NX = XMAX * (TWO ? 2 : 1);          // vector-memory instructions of one X(c) per wave (branch-free => exact)
+  auto taps = [&](int buf, int j0, int j1) {
     const float* wb = wl + buf * WBUF;
     const float* xb = xl + buf * a.xl_floats;
     auto tap = [&](int j, int dy, int dx) {
@@ -500,16 +493,43 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
           acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[m][b], 0, 0, 0);
     };
     if (KIND == KIND_GATHER) {
-      // compile-time trip count: the operand reads of tap j+1 are scheduled under the MFMAs of tap j
 #pragma unroll
-      for (int j = 0; j < 9; ++j) tap(j, (j / 3) * a.dil, (j % 3) * a.dil);
+      for (int j = 0; j < 9; ++j)
+        if (j >= j0 && j < j1) tap(j, (j / 3) * a.dil, (j % 3) * a.dil);
     } else {
-      for (int j = 0; j < ntaps; ++j) {
+      for (int j = j0; j < j1 && j < ntaps; ++j) {
         const int jy = j / nxt, jx = j - jy * nxt;
         if (KIND == KIND_TPHASE) tap(j, ti.py ? (jy ? 0 : 1) : 0, ti.px ? (jx ? 0 : 1) : 0);
         else tap(j, jy, jx);
       }
     }
+  };
+  if (!dbg_nostage) {
+    dma_w(0, 0);
+    load_x(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    write_x(0, 0);
+    if (nchunks > 1) load_x(CK);                     // X(1)
+  }
+  const int jsplit = KIND == KIND_GATHER ? 5 : (ntaps + 1) / 2;
+  for (int i = 0; i < nchunks; ++i) {
+    const int buf = i & 1;
+    // F(i) must have landed; the only younger requests of this wave are the NX loads of X(i+1)
+    if (i + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // xl[buf] complete (written during iteration i-1), F(i) visible, buffers buf^1 retired by every wave.  A bare barrier: the fence
+    // of __syncthreads() would drain vmcnt(0), i.e. wait for the X(i+1) loads this pipeline wants to keep in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool more = i + 1 < nchunks && !dbg_nostage;
+    if (more) dma_w(buf ^ 1, (i + 1) * CK);           // F(i+1), lands during this iteration
+    if (!dbg_nomfma) taps(buf, 0, jsplit);
+    if (more) {
+      write_x(buf ^ 1, (i + 1) * CK);                 // the compiler waits for X(i+1) with a counted vmcnt (WU younger DMA requests)
+      if (i + 2 < nchunks) load_x((i + 2) * CK);      // X(i+2)
+    }
+    if (!dbg_nomfma) taps(buf, jsplit, 9);
   }
   conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND>(a, ti, acc, red, tid);
 }
