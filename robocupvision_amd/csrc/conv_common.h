@@ -25,6 +25,7 @@ struct ConvArgs {
   int in_mode, stats;
   uint32_t flags;
   int wl_floats, xl_floats;    // LDS carve: filter tile, input tile (then constants, then reduction scratch)
+  int xpitch;                  // floats per staged input pixel (see conv_xpitch)
   FastDiv fdWt, fdIW;
 };
 
@@ -92,6 +93,12 @@ struct ConvPlan {
   int WM, WN, XMAX;      // narrow kernel template selection
   int first;             // 1: conv_first.hip (3 -> 8 channel first layer on the vector ALU)
 };
+
+// LDS pitch of a staged input pixel holding CK channels.  The B operand of v_mfma_f32_16x16x4_f32 is read with ds_read_b32 at
+// (pixel(l15) * IS * pitch + l4): 16 pixels x 2 channel lanes per 32-lane half must fall on 32 different banks.  Unit-stride pixel
+// blocks: pitch = CK + 2 (pitch/2 odd => 16 distinct even banks, + l4 the odd ones); stride-2 blocks: the lane stride is 2*pitch,
+// so pitch = CK + 1 (odd).  (CK + 1 everywhere cost 46 % of all LDS cycles in bank conflicts on the unit-stride layers.)
+static inline int conv_xpitch(int CK, int pixel_stride) { return pixel_stride == 1 ? CK + 2 : CK + 1; }
 
 static inline void tile_halo(int kind, int R, int Wt, int s, int d, int* IH, int* IW) {
   if (kind == KIND_GATHER) { *IH = (R - 1) * s + 2 * d + 1; *IW = (Wt - 1) * s + 2 * d + 1; }

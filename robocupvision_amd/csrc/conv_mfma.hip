@@ -35,7 +35,7 @@
 // loads per thread are issued before any is consumed (one load in flight per thread is latency bound).
 template <int MODE, int CK, int NT>
 __device__ __forceinline__ void stage_input(const ConvArgs& a, float* xl, const float* cl, const TileInfo& ti, int c0, int tid) {
-  constexpr int S = CK + 1;
+  const int S = a.xpitch;
   constexpr int Q = CK / 4;
   constexpr int STEP = NT / Q;
   constexpr int UNR = 4;
@@ -222,7 +222,7 @@ template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, int KIND>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int COT = WM * WAVES_M * 16;
-  constexpr int S = CK + 1;
+  const int S = a.xpitch;
   constexpr int WS = COT + 16;
   constexpr int C4 = COT / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -356,7 +356,8 @@ template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND, bool TWO>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const ConvArgs a) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int COT = WM * WAVES_M * 16;
-  constexpr int CK = 4, S = CK + 1;
+  constexpr int CK = 4;
+  const int S = a.xpitch;
   constexpr int WS = COT;                       // unpadded rows: the DMA image is lane-linear
   constexpr int C4 = COT / 4;
   constexpr int XMAX = 4, AMAX = TWO ? XMAX : 1;
@@ -717,11 +718,11 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   if (pl->dma) {
     pl->CK = 4;
     pl->wl_floats = ntaps * 4 * tc.cot();
-    pl->xl_floats = round_up(pl->IH * pl->IW * 5, 4);
+    pl->xl_floats = round_up(pl->IH * pl->IW * conv_xpitch(4, pl->kind == KIND_GATHER ? s : 1), 4);
     floats = 2 * (size_t)pl->wl_floats + 2 * (size_t)pl->xl_floats + 5 * CinP + 16 + (size_t)tc.WAVES_N * 2 * tc.cot();
   } else {
     pl->wl_floats = round_up(ntaps * pl->CK * (tc.cot() + 16), 4);
-    pl->xl_floats = round_up(pl->IH * pl->IW * (pl->CK + 1), 4);
+    pl->xl_floats = round_up(pl->IH * pl->IW * conv_xpitch(pl->CK, pl->kind == KIND_GATHER ? s : 1), 4);
     floats = (size_t)pl->wl_floats + pl->xl_floats + 5 * CinP + 16 + (size_t)tc.WAVES_N * 2 * tc.cot();
   }
   pl->lds = floats * sizeof(float);
@@ -777,6 +778,7 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   a.total_tiles = pl.total_tiles; a.nchunks = a.CinP / pl.CK;
   a.in_mode = op->i[RCV_I_INMODE]; a.stats = op->i[RCV_I_STATS]; a.flags = op->flags;
   a.wl_floats = pl.wl_floats; a.xl_floats = pl.xl_floats;
+  a.xpitch = conv_xpitch(pl.CK, pl.kind == KIND_GATHER ? a.stride : 1);
   a.fdWt = make_fastdiv(pl.Wt); a.fdIW = make_fastdiv(pl.IW);
   RCV_CHECK_ARG(a.in && a.w && a.out, "conv: null operand");
   RCV_CHECK_ARG(a.in_mode == RCV_LOAD_PLAIN || a.in_mode == RCV_LOAD_NCHW || a.in_c, "conv: load mode %d needs constants", a.in_mode);

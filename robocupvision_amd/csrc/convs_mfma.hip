@@ -17,15 +17,11 @@
 #include <stdlib.h>
 #include "conv_common.h"
 
-template <int CK>
-struct NarrowPitch {          // LDS floats per staged pixel: odd-ish pitch that spreads the 16 pixels of a block over the banks
-  static constexpr int value = CK == 32 ? 37 : CK + 1;
-};
-
 template <int MODE, int XMAX, int AMAX, int CK>
 __device__ __forceinline__ void narrow_write_x(const ConvArgs& a, float* xl, const float* cl, const float4 (&px)[XMAX],
                                                const float4 (&pa)[AMAX], uint32_t okmask, int tid) {
-  constexpr int S = NarrowPitch<CK>::value, Q = CK / 4, STEP = 256 / Q;
+  constexpr int Q = CK / 4, STEP = 256 / Q;
+  const int S = a.xpitch;
   const int q = tid % Q;
   const int npix = a.IH * a.IW;
   float4 k[5];
@@ -49,7 +45,7 @@ template <int WM, int WN, int CK, int KIND, int XMAX, bool TWO>
 __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
   constexpr int NT = 256, WAVES = 4;
   constexpr int COT = WM * 16;
-  constexpr int S = NarrowPitch<CK>::value;
+  const int S = a.xpitch;
   constexpr int WS = COT + 16;
   constexpr int Q = CK / 4;
   constexpr int STEP = NT / Q;
@@ -371,7 +367,7 @@ int convs_make_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* p
   RCV_CHECK_ARG(best >= 0, "conv (narrow): no tile fits %dx%d", TH, TW);
   pl->tiles_x = ceil_div(TW, pl->Wt); pl->tiles_y = ceil_div(TH, pl->R);
   tile_halo(kind, pl->R, pl->Wt, s, d, &pl->IH, &pl->IW);
-  const int S = CinP == 32 ? 37 : CinP + 1;
+  const int S = conv_xpitch(CinP, kind == KIND_GATHER ? s : 1);
   pl->wl_floats = round_up(ntaps * CinP * (pl->CoutP + 16), 4);
   pl->xl_floats = round_up(pl->IH * pl->IW * S, 4);
   const size_t floats = (size_t)pl->wl_floats + pl->xl_floats + 5 * CinP + 16 + (size_t)4 * 2 * pl->CoutP;
