@@ -117,6 +117,10 @@ enum {
 #define RCV_F_FUSED_UP   512u  /* CLS_FWD / CLS_BWD: the input is the decoder output relu(t*c0+c1) + f(r), formed on the fly from t (p[IN] resp.
                                * p[EPI_AUX]), its constants (p[IN_C] resp. p[EPI_C]), the skip tensor p[X3], its constants p[X4], i[AUX0] = its
                                * load mode -- RCV_OP_COMBINE is then not needed for this value                                             */
+#define RCV_F_FUSED_CE   1024u /* with RCV_F_FUSED_UP: CLS_FWD also produces the weighted cross entropy (p[IN2] = int64 target, p[X0] = class weights or
+                               * NULL, p[PART], p[X1] = float[4] loss_out as RCV_OP_CE_FWD, p[X2] = uint8 arg-max or NULL); CLS_BWD forms d loss / d logits
+                               * itself (p[IN2] = target, p[X0] = class weights, p[BIAS], p[X5] = loss_out, p[IN2_AUX] = d loss scalar): the
+                               * logits gradient tensor and RCV_OP_CE_BWD are not needed                                              */
 #define RCV_F_SIDE_STREAM (1u << 16) /* rcv_run: enqueue this op on the handle's side stream (forked from / joined to the caller's
                                       * stream inside the call): ops off the critical path, e.g. the filter gradients of backward */
 #define RCV_F_CONCAT    256u  /* COMBINE: out[..,0:C] = relu(t*s+h), out[..,C:2C] = f(r)  (v2 skip concat, model.py:507) */

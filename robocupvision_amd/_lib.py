@@ -24,6 +24,7 @@ LOAD_PLAIN, LOAD_AFFINE, LOAD_GRAD_ENC, LOAD_GRAD_DEC, LOAD_NCHW, LOAD_AFFINE_RE
 STATS_NONE, STATS_FWD, STATS_BWD_ENC, STATS_BWD_DEC = range(4)
 F_BIAS, F_RELU, F_RESID, F_OUT_NCHW, F_FLIP, F_TRANSPOSED_SRC, F_ARGMAX, F_TRAINING, F_CONCAT = 1, 2, 4, 8, 16, 32, 64, 128, 256
 F_FUSED_UP = 512
+F_FUSED_CE = 1024
 F_SIDE_STREAM = 1 << 16
 
 

@@ -190,6 +190,7 @@ __global__ void concat_kernel(const float* __restrict__ t, const float* __restri
 // 1x1 classifier (model.py:411): NHWC [.,CIN] -> NCHW logits [N][COUT][H][W]
 // ------------------------------------------------------------------------------------------
 #define CLS_MAX_OUT 8
+#define CE_MAX_C 8
 // FUSED: the classifier input up = relu(t*c0+c1) + f(r) (decoder block output + skip, model.py:509) is formed here from the
 // block's raw tensors instead of being materialised by RCV_OP_COMBINE (saves one tensor write and one read at full resolution).
 template <int CIN, bool FUSED>
@@ -214,19 +215,26 @@ __device__ __forceinline__ void cls_load_up(float (&v)[CIN], const float* __rest
   }
 }
 
-template <int CIN, bool FUSED>
+// CE: the weighted cross-entropy partial sums, the arg-max mask and the pixel-accuracy count of RCV_OP_CE_FWD are taken from the
+// logits while they are still in registers (same pixel -> thread assignment and summation order as ce_fwd_kernel: bit-identical loss).
+template <int CIN, bool FUSED, bool CE>
 __global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                float* __restrict__ out, int N, int HW, int COUT, const float* __restrict__ tc,
-                               const float* __restrict__ r, const float* __restrict__ rc, int mode2) {
+                               const float* __restrict__ r, const float* __restrict__ rc, int mode2,
+                               const int64_t* __restrict__ target, const float* __restrict__ cw, float* __restrict__ part,
+                               uint8_t* __restrict__ argmax) {
   __shared__ float ws[CLS_MAX_OUT * CIN + CLS_MAX_OUT];
+  __shared__ double sh[3][4];
   for (int e = threadIdx.x; e < COUT * CIN; e += blockDim.x) ws[e] = w[e];
   for (int e = threadIdx.x; e < COUT; e += blockDim.x) ws[CLS_MAX_OUT * CIN + e] = bias ? bias[e] : 0.f;
   __syncthreads();
+  double a_nll = 0.0, a_w = 0.0, a_ok = 0.0;
   const size_t total = (size_t)N * HW;
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
     float v[CIN];
     cls_load_up<CIN, FUSED>(v, x, tc, r, rc, mode2, p);
     const size_t n = p / HW, hw = p % HW;
+    float lg[CLS_MAX_OUT];
 #pragma unroll
     for (int c = 0; c < CLS_MAX_OUT; ++c) {
       if (c < COUT) {
@@ -234,18 +242,53 @@ __global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restr
 #pragma unroll
         for (int k = 0; k < CIN; ++k) u = fmaf(v[k], ws[c * CIN + k], u);
         out[(n * COUT + c) * HW + hw] = u;
+        lg[c] = u;
       }
+    }
+    if (CE) {
+      float mx = -INFINITY;
+      int am = 0;
+#pragma unroll
+      for (int c = 0; c < CLS_MAX_OUT; ++c) if (c < COUT && lg[c] > mx) { mx = lg[c]; am = c; }
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < CLS_MAX_OUT; ++c) if (c < COUT) se += expf(lg[c] - mx);
+      const int tg = (int)target[p];
+      float vt = 0.f;
+#pragma unroll
+      for (int c = 0; c < CLS_MAX_OUT; ++c) if (c == tg) vt = lg[c];
+      const float wt = cw ? cw[tg] : 1.f;
+      const float nll = (mx - vt) + logf(se);
+      a_nll += (double)(wt * nll);
+      a_w += (double)wt;
+      a_ok += (am == tg) ? 1.0 : 0.0;
+      if (argmax) argmax[p] = (uint8_t)am;
+    }
+  }
+  if (CE) {
+    a_nll = wave_sum_d(a_nll); a_w = wave_sum_d(a_w); a_ok = wave_sum_d(a_ok);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wv] = a_nll; sh[1][wv] = a_w; sh[2][wv] = a_ok; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      double t = 0.0;
+      for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[threadIdx.x][i];
+      part[(size_t)blockIdx.x * 3 + threadIdx.x] = (float)t;
     }
   }
 }
 
 // classifier backward: d_up[p][k] = sum_c dl[c][p] W[c][k];  dW[c][k] = sum_p dl[c][p] up[p][k];
 // db[c] = sum_p dl[c][p];  optional decoder BN-backward statistics of d_up against t.
-template <int CIN, int COUT, bool FUSED>
+// CE: d loss / d logits is recomputed from (t, r, W, b, target) instead of being read: RCV_OP_CE_BWD and its tensor disappear (the
+// logits are re-formed with the forward's FMA order, so the gradients are bit-identical to the unfused path).
+template <int CIN, int COUT, bool FUSED, bool CE>
 __global__ __launch_bounds__(256, 2) void cls_bwd_kernel(const float* __restrict__ up, const float* __restrict__ dl, const float* __restrict__ w,
                                float* __restrict__ dup, const float* __restrict__ t, const float* __restrict__ tc,
                                float* __restrict__ stat_part, float* __restrict__ w_part, int N, int HW, int stats,
-                               const float* __restrict__ r, const float* __restrict__ rc, int mode2) {
+                               const float* __restrict__ r, const float* __restrict__ rc, int mode2,
+                               const int64_t* __restrict__ target, const float* __restrict__ cw, const float* __restrict__ bias,
+                               const float* __restrict__ loss_out, const float* __restrict__ grad_out) {
   __shared__ float ws[COUT * CIN];
   __shared__ float red[4][COUT * CIN + COUT + 2 * CIN];
   for (int e = threadIdx.x; e < COUT * CIN; e += blockDim.x) ws[e] = w[e];
@@ -261,9 +304,29 @@ __global__ __launch_bounds__(256, 2) void cls_bwd_kernel(const float* __restrict
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
     const size_t n = p / HW, hw = p % HW;
     float g[COUT], u[CIN], d[CIN];
-#pragma unroll
-    for (int c = 0; c < COUT; ++c) g[c] = dl[(n * COUT + c) * HW + hw];
     cls_load_up<CIN, FUSED>(u, FUSED ? t : up, tc, r, rc, mode2, p);      // FUSED: up is re-formed from t and the skip tensor
+    if (CE) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) {
+        float lgc = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CIN; ++k) lgc = fmaf(u[k], ws[c * CIN + k], lgc);
+        g[c] = lgc;
+        mx = fmaxf(mx, lgc);
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) { g[c] = expf(g[c] - mx); se += g[c]; }
+      const int tg = (int)target[p];
+      const float kf = (grad_out[0] / loss_out[1]) * (cw ? cw[tg] : 1.f);
+      const float inv = 1.f / se;
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) g[c] = __fmul_rn(kf, fmaf(g[c], inv, c == tg ? -1.f : 0.f));      // explicit: same rounding as ce_bwd_kernel
+    } else {
+#pragma unroll
+      for (int c = 0; c < COUT; ++c) g[c] = dl[(n * COUT + c) * HW + hw];
+    }
 #pragma unroll
     for (int k = 0; k < CIN; ++k) {
       float acc = 0.f;
@@ -349,7 +412,6 @@ __global__ void rows_reduce_kernel(const float* __restrict__ part, int n_rows, i
 // ------------------------------------------------------------------------------------------
 // CrossEntropyLoss2d (model.py:76-82) + argmax / pixel accuracy (train.py:70-71)
 // ------------------------------------------------------------------------------------------
-#define CE_MAX_C 8
 __global__ void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, const float* __restrict__ cw,
                               int N, int C, int HW, float* __restrict__ part, uint8_t* __restrict__ argmax) {
   __shared__ double sh[3][4];
@@ -430,7 +492,7 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* _
     const float inv = 1.f / se;
 #pragma unroll
     for (int c = 0; c < CE_MAX_C; ++c)
-      if (c < C) dlogits[(n * C + c) * HW + hw] = k * (v[c] * inv - (c == tg ? 1.f : 0.f));
+      if (c < C) dlogits[(n * C + c) * HW + hw] = __fmul_rn(k, fmaf(v[c], inv, c == tg ? -1.f : 0.f));   // explicit: same rounding as cls_bwd_kernel<CE>
   }
 }
 
@@ -899,21 +961,35 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       break;
     }
     case RCV_OP_CLS_FWD: {
-      if (query) return RCV_OK;
+      const bool fused = (op->flags & RCV_F_FUSED_UP) != 0, with_ce = (op->flags & RCV_F_FUSED_CE) != 0;
+      const int gce = reduce_grid(h, (size_t)N * H * W, 256);      // with the loss: one partial row per workgroup, same grid as RCV_OP_CE_FWD
+      if (query) {
+        if (with_ce) { query->n_part = gce; query->part_bytes = (size_t)gce * 3 * sizeof(float); }
+        return RCV_OK;
+      }
       RCV_CHECK_ARG((Cin == 8 || Cin == 16) && Cout >= 1 && Cout <= CLS_MAX_OUT, "classifier: Cin=%d Cout=%d unsupported", Cin, Cout);
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_W] && op->p[RCV_P_OUT], "classifier: null operand");
       const int g = stream_grid(h, (size_t)N * H * W, 256);
-      const bool fused = (op->flags & RCV_F_FUSED_UP) != 0;
       const float* tc = (const float*)op->p[RCV_P_IN_C]; const float* r = (const float*)op->p[RCV_P_X3]; const float* rc = (const float*)op->p[RCV_P_X4];
       const int mode2 = op->i[RCV_I_AUX0];
+      const int64_t* tgt = (const int64_t*)op->p[RCV_P_IN2]; const float* cw = (const float*)op->p[RCV_P_X0];
+      float* part = (float*)op->p[RCV_P_PART]; uint8_t* am = (uint8_t*)op->p[RCV_P_X2];
       if (fused) {
         RCV_CHECK_ARG(Cin == 8 && tc && r && (mode2 == RCV_LOAD_PLAIN || rc), "classifier (fused decoder output): operands missing");
         RCV_CHECK_ARG(mode2 == RCV_LOAD_PLAIN || mode2 == RCV_LOAD_AFFINE || mode2 == RCV_LOAD_AFFINE_RELU, "classifier: skip load mode %d", mode2);
-        hipLaunchKernelGGL((cls_fwd_kernel<8, true>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2);
+      }
+      if (with_ce) {
+        RCV_CHECK_ARG(fused && Cout <= CE_MAX_C && tgt && part && op->p[RCV_P_X1], "classifier + cross entropy: needs the fused decoder input, target, workspace, loss_out");
+        RCV_CHECK_ARG(op->i[RCV_I_NPART] == gce, "classifier + cross entropy: workspace rows %d != %d", op->i[RCV_I_NPART], gce);
+        hipLaunchKernelGGL((cls_fwd_kernel<8, true, true>), dim3(gce), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am);
+        RCV_HIP(hipGetLastError());
+        hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)part, gce, (float*)op->p[RCV_P_X1]);
+      } else if (fused) {
+        hipLaunchKernelGGL((cls_fwd_kernel<8, true, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am);
       } else if (Cin == 8)
-        hipLaunchKernelGGL((cls_fwd_kernel<8, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2);
+        hipLaunchKernelGGL((cls_fwd_kernel<8, false, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am);
       else
-        hipLaunchKernelGGL((cls_fwd_kernel<16, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2);
+        hipLaunchKernelGGL((cls_fwd_kernel<16, false, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am);
       break;
     }
     case RCV_OP_CLS_BWD: {
@@ -936,15 +1012,25 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       float* w_part = stat_part + (size_t)g * 2 * Cin;
       const float* r = (const float*)op->p[RCV_P_X3]; const float* rc = (const float*)op->p[RCV_P_X4];
       const int mode2 = op->i[RCV_I_AUX0];
-      if (fused) {
+      const bool with_ce = (op->flags & RCV_F_FUSED_CE) != 0;
+      const int64_t* tgt = (const int64_t*)op->p[RCV_P_IN2]; const float* cw = (const float*)op->p[RCV_P_X0];
+      const float* bias = (const float*)op->p[RCV_P_BIAS]; const float* loss_out = (const float*)op->p[RCV_P_X5];
+      const float* grad_out = (const float*)op->p[RCV_P_IN2_AUX];
+      if (with_ce) {
+        RCV_CHECK_ARG(fused && stats == RCV_STATS_BWD_DEC && r && (mode2 == RCV_LOAD_PLAIN || rc) && tgt && loss_out && grad_out,
+                      "classifier + cross entropy backward: operands missing");
+        hipLaunchKernelGGL((cls_bwd_kernel<8, 5, true, true>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)nullptr,
+                           (const float*)op->p[RCV_P_W], (float*)op->p[RCV_P_OUT], (const float*)op->p[RCV_P_EPI_AUX],
+                           (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats, r, rc, mode2, tgt, cw, bias, loss_out, grad_out);
+      } else if (fused) {
         RCV_CHECK_ARG(stats == RCV_STATS_BWD_DEC && r && (mode2 == RCV_LOAD_PLAIN || rc), "classifier backward (fused decoder output): operands missing");
-        hipLaunchKernelGGL((cls_bwd_kernel<8, 5, true>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
+        hipLaunchKernelGGL((cls_bwd_kernel<8, 5, true, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
                            (const float*)op->p[RCV_P_W], (float*)op->p[RCV_P_OUT], (const float*)op->p[RCV_P_EPI_AUX],
-                           (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats, r, rc, mode2);
+                           (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats, r, rc, mode2, tgt, cw, bias, loss_out, grad_out);
       } else {
-        hipLaunchKernelGGL((cls_bwd_kernel<8, 5, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
+        hipLaunchKernelGGL((cls_bwd_kernel<8, 5, false, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
                            (const float*)op->p[RCV_P_W], (float*)op->p[RCV_P_OUT], (const float*)op->p[RCV_P_EPI_AUX],
-                           (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats, r, rc, mode2);
+                           (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats, r, rc, mode2, tgt, cw, bias, loss_out, grad_out);
       }
       RCV_HIP(hipGetLastError());
       // dW -> p[X1] ([Cout][Cin]), db -> p[X2]

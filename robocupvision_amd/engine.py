@@ -143,6 +143,7 @@ class Plan:
         self.logits: Optional[torch.Tensor] = None
         self.input_grads: List[Optional[torch.Tensor]] = []
         self.bwd_marks: List = []            # [(ops executed, lowest final flat-gradient offset)]
+        self.ce = None                       # lazily built op lists with the cross entropy fused into the classifier ops
         self.bytes = 0
 
 
@@ -746,23 +747,93 @@ class Engine:
             dlogits = dlogits.to(torch.float32).contiguous()
         for (idx, slot) in plan.dlogits_slots:
             plan.bwd.arr[idx].p[slot] = dlogits.data_ptr()
+        self._run_backward(plan, plan.bwd)
+        return plan
+
+    def _run_backward(self, plan: Plan, ops: L.OpList):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if self.grad_ready_cb is None or not plan.bwd_marks:
-            plan.bwd.run(self.handle, stream)
-            return plan
+            ops.run(self.handle, stream)
+            return
         # bucketed: run the op list in slices and hand finished gradient ranges to the caller (all-reduce on a side stream).  The
         # slices do not join the filter-gradient stream back (that would stall the d(activation) chain at every bucket border): the
         # callback makes ITS stream wait for it (join_side), the compute stream joins once at the end.
         done, hi = 0, self.flat.numel
         for (end, lo) in select_buckets(plan.bwd_marks, self.flat.numel, self.grad_buckets):
-            plan.bwd.run_slice(self.handle, stream, done, end, join=False)
+            ops.run_slice(self.handle, stream, done, end, join=False)
             done = end
             if lo < hi:
                 self.grad_ready_cb(lo, hi)
                 hi = lo
-        if done < plan.bwd.n:
-            plan.bwd.run_slice(self.handle, stream, done, plan.bwd.n, join=False)
+        if done < ops.n:
+            ops.run_slice(self.handle, stream, done, ops.n, join=False)
         if hi > 0:
             self.grad_ready_cb(0, hi)
         L.join_side(self.handle, stream)
+
+    # ------------------------------------------------------------------ loss fused into the classifier (Trainer fast path)
+    def _ce_variant(self, plan: Plan):
+        """Copies of the plan's op lists in which the fused 1x1 classifier also evaluates CrossEntropyLoss2d (forward) and forms
+        d loss / d logits itself (backward): RCV_F_FUSED_CE.  None when the graph does not end in that classifier."""
+        if plan.ce is not None:
+            return plan.ce or None
+        plan.ce = False
+        if plan.bwd is None or plan.bwd.n == 0:
+            return None
+        kf = [k for k in range(plan.fwd.n) if plan.fwd.arr[k].kind == L.OP_CLS_FWD and plan.fwd.arr[k].flags & L.F_FUSED_UP]
+        kb = [k for k in range(plan.bwd.n) if plan.bwd.arr[k].kind == L.OP_CLS_BWD and plan.bwd.arr[k].flags & L.F_FUSED_UP]
+        if len(kf) != 1 or len(kb) != 1 or kf[0] != plan.fwd.n - 1 or kb[0] != 0:
+            return None
+        fops = [L.RcvOp.from_buffer_copy(plan.fwd.arr[k]) for k in range(plan.fwd.n)]
+        bops = [L.RcvOp.from_buffer_copy(plan.bwd.arr[k]) for k in range(plan.bwd.n)]
+        f, b = fops[kf[0]], bops[kb[0]]
+        N, H, W = f.i[L.RCV_I_N], f.i[L.RCV_I_H], f.i[L.RCV_I_W]
+        loss_out = self._zeros(plan, 4)
+        argmax = self._alloc(plan, N, H, W, dtype=torch.uint8)
+        gone = torch.ones(1, dtype=torch.float32, device=self.device)
+        plan.keep.append(gone)
+        f.flags |= L.F_FUSED_CE
+        f.p[L.RCV_P_X1] = loss_out.data_ptr()
+        f.p[L.RCV_P_X2] = argmax.data_ptr()
+        self._workspace(plan, f)
+        b.flags |= L.F_FUSED_CE
+        b.p[L.RCV_P_BIAS] = f.p[L.RCV_P_BIAS]
+        b.p[L.RCV_P_X5] = loss_out.data_ptr()
+        b.p[L.RCV_P_IN2_AUX] = gone.data_ptr()
+        plan.ce = {"fwd": L.OpList(fops), "bwd": L.OpList(bops), "kf": kf[0], "kb": kb[0], "loss_out": loss_out, "argmax": argmax}
+        return plan.ce
+
+    def forward_ce(self, inputs: Sequence[torch.Tensor], targets: torch.Tensor, weight: Optional[torch.Tensor]):
+        """Training forward with CrossEntropyLoss2d(weight) fused into the classifier op.  Returns (logits, loss_out[4], argmax) --
+        loss_out as RCV_OP_CE_FWD: [loss, sum_w, #correct, sum_w*nll] -- or None when this graph has no such fast path."""
+        for t in inputs:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise L.RcvError("engine inputs must be contiguous float32 tensors")
+        plan = self._plan_for(inputs, True)
+        ce = self._ce_variant(plan)
+        if ce is None:
+            return None
+        N, H, W = ce["argmax"].shape
+        if targets.dtype != torch.int64 or not targets.is_contiguous() or tuple(targets.shape) != (N, H, W) or targets.device != self.device:
+            raise L.RcvError("targets must be a contiguous int64 [B,H,W] tensor on the model's device")
+        for k, t in enumerate(inputs):
+            for (is_bwd, idx, slot) in plan.input_slots[k]:
+                (ce["bwd"] if is_bwd else ce["fwd"]).arr[idx].p[slot] = t.data_ptr()
+                (plan.bwd if is_bwd else plan.fwd).arr[idx].p[slot] = t.data_ptr()      # keeps the plain lists usable (profile_last)
+        wptr = None if weight is None else weight.data_ptr()
+        for op in (ce["fwd"].arr[ce["kf"]], ce["bwd"].arr[ce["kb"]]):
+            op.p[L.RCV_P_IN2] = targets.data_ptr()
+            op.p[L.RCV_P_X0] = wptr
+        ce["fwd"].run(self.handle, torch.cuda.current_stream(self.device).cuda_stream)
+        nbt = [m.num_batches_tracked for m in self.bn_modules if m.num_batches_tracked is not None]
+        if nbt:
+            torch._foreach_add_(nbt, 1)
+        self._last = (plan, [t for t in inputs])
+        self._last_ce = (targets, weight)        # keep alive until backward_ce
+        return plan.logits, ce["loss_out"], ce["argmax"]
+
+    def backward_ce(self):
+        """Backward of the loss produced by the last forward_ce (d loss = 1): fills the flat gradient buffer."""
+        plan, _inputs = self._last
+        self._run_backward(plan, plan.ce["bwd"])
         return plan

@@ -28,7 +28,7 @@ from .optim import AdamL1
 class Trainer:
     def __init__(self, model, class_weights: Optional[Sequence[float]] = (1, 10, 30, 10, 2), lr: float = 1e-3,
                  decay: float = 1e-6, transfer: int = 0, distributed: bool = False, overlap: bool = True,
-                 use_dice: bool = False, optimizer=None):
+                 use_dice: bool = False, optimizer=None, fuse_loss: bool = True):
         self.model = model
         dev = next(model.parameters()).device
         if dev.type != "cuda":
@@ -45,6 +45,7 @@ class Trainer:
         self.optimizer = optimizer if optimizer is not None else AdamL1(model, lr=lr, decay=decay, transfer=transfer)
         self.metrics = torch.zeros(4, dtype=torch.float64, device=dev)     # loss, reg, correct, steps
         self.distributed = distributed
+        self.fuse_loss = fuse_loss and not os.environ.get("RCV_NO_FUSED_LOSS")
         self.world = 1
         self.comm_stream = None
         self.force_collectives = bool(int(os.environ.get("RCV_FORCE_COLLECTIVES", "0")))   # exercise the path at world size 1
@@ -84,12 +85,31 @@ class Trainer:
         model, opt, crit = self.model, self.optimizer, self.criterion
         model.train()
         opt.zero_grad(set_to_none=True)
-        pred = model(imgs)
-        ce = crit(pred, targets)
         self._pending = None
         eng = model._get_engine()
         eng.grad_ready_cb = self._grad_ready if (self.distributed and (self.world > 1 or self.force_collectives)) else None
-        ce.backward()
+        fused = None
+        if self.fuse_loss and type(crit) is CrossEntropyLoss2d and imgs.dtype == torch.float32 and imgs.is_contiguous():
+            # fast path: the loss is evaluated inside the classifier op and its gradient inside the classifier's backward op
+            # (no logits-gradient tensor, no separate loss kernels, no autograd graph); bit-identical to the path below
+            w = crit.weight
+            if w is not None and w.device != imgs.device:
+                w = w.to(imgs.device)
+                crit.weight = w
+            fused = eng.forward_ce([imgs], targets.to(torch.int64).contiguous(), w)
+        if fused is not None:
+            pred, out, argmax = fused
+            crit.last_stats, crit.last_argmax = out, argmax
+            ce = out[0]
+            eng.backward_ce()
+            fl = eng.flat
+            for k, p in enumerate(fl.params):
+                if eng.param_used[k]:
+                    p.grad = fl.grad_view(k)
+        else:
+            pred = model(imgs)
+            ce = crit(pred, targets)
+            ce.backward()
         with torch.no_grad():
             reg = opt.l1_term() if hasattr(opt, "l1_term") else torch.zeros((), device=self.device)
             self.metrics += torch.stack([ce.detach().double() + reg.double(), reg.double(),

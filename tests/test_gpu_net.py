@@ -325,3 +325,24 @@ def test_single_value_batchnorm_raises_like_the_reference():
     model.eval()
     with torch.no_grad():
         assert model(torch.zeros(1, 3, 16, 16, device=DEV)).shape == (1, 5, 16, 16)
+
+
+def test_trainer_fused_loss_is_bitwise_identical(net_kats):
+    """Trainer fast path (cross entropy evaluated inside the classifier ops, RCV_F_FUSED_CE) against the module-by-module path:
+    same loss, same metrics, bit-identical parameters after two steps."""
+    from robocupvision_amd.train import Trainer
+    tag = "robo_l_1x48x64"
+    x, t = _t(net_kats[tag + "/x"]).to(DEV), _t(net_kats[tag + "/t"]).to(DEV)
+    res = []
+    for fuse in (True, False):
+        model = build(dict(noScale=True)).to(DEV)
+        tr = Trainer(model, class_weights=CE_W, lr=1e-3, decay=1e-6, fuse_loss=fuse)
+        tr.step(x, t)
+        pred = tr.step(x, t).clone()
+        assert (model._get_engine()._last[0].ce not in (None, False)) == fuse      # the fast path really ran / really did not
+        res.append((tr.pop_metrics(), pred, {k: v.clone() for k, v in model.state_dict().items()}, tr.criterion.last_argmax.clone()))
+    (ma, pa, sa, aa), (mb, pb, sb, ab) = res
+    assert ma == mb
+    assert torch.equal(pa, pb) and torch.equal(aa, ab)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
