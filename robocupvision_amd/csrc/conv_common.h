@@ -4,7 +4,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { KIND_GATHER = 0, KIND_TPHASE = 1, KIND_TMERGED = 2 };
+enum { KIND_GATHER = 0, KIND_TPHASE = 1, KIND_TMERGED = 2, KIND_TALL = 3 };   // TALL: all four output parities of a transposed conv in one workgroup
 
 struct ConvArgs {
   const float* in;

@@ -361,7 +361,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   constexpr int WS = COT;                       // unpadded rows: the DMA image is lane-linear
   constexpr int C4 = COT / 4;
   constexpr int XMAX = 4, AMAX = TWO ? XMAX : 1;
-  constexpr int NTAPS_MAX = KIND == KIND_GATHER ? 9 : 4;
+  constexpr int NTAPS_MAX = (KIND == KIND_GATHER || KIND == KIND_TALL) ? 9 : 4;
+  constexpr int NPH = KIND == KIND_TALL ? 4 : 1;  // accumulator sets (output parities handled by this workgroup)
   constexpr int WBUF = NTAPS_MAX * CK * WS;     // floats per filter buffer
   constexpr int WU = (NTAPS_MAX * CK * C4 + NT - 1) / NT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   int nxt = 3, ntaps = 9;
   if (KIND == KIND_TPHASE) { nxt = 1 + ti.px; ntaps = (1 + ti.py) * nxt; }
   if (KIND == KIND_TMERGED) { nxt = 2; ntaps = 4; }
+  if (KIND == KIND_TALL) { nxt = 3; ntaps = 9; }
   const int IS = KIND == KIND_GATHER ? a.stride : 1;
   const int wtotal = ntaps * CK * C4;           // 16-byte pieces of one filter chunk (a multiple of 64 for COT >= 64)
 
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
       int e0 = (u * (NT / 64) + wave) * 64;                 // first piece of this wave-instruction (wave uniform)
-      if (e0 >= wtotal) e0 = wtotal - 64;                   // every wave issues exactly WU instructions (a duplicate piece rewrites the
+      if (e0 + 64 > wtotal) e0 = wtotal - 64;               // every wave issues exactly WU instructions (a duplicate piece rewrites the
       {                                                     // same bytes): the counted s_waitcnt of the pipelined loop relies on it
         const int e = e0 + lane;
         const int row = e / C4, c4 = e % C4;
@@ -463,11 +465,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   }
   const int aoff = l4 * WS + (wave_m * WM) * 16 + l15;
 
-  f32x4 acc[WM][WN];
+  f32x4 acc[NPH][WM][WN];
 #pragma unroll
-  for (int m = 0; m < WM; ++m)
+  for (int ph = 0; ph < NPH; ++ph)
 #pragma unroll
-    for (int b = 0; b < WN; ++b) acc[m][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int b = 0; b < WN; ++b) acc[ph][m][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bool dbg_nostage = a.flags & RCV_F_DBG_NOSTAGE, dbg_nomfma = a.flags & RCV_F_DBG_NOMFMA;
   const int nchunks = a.CinP / CK;
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   auto taps = [&](int buf, int j0, int j1) {
     const float* wb = wl + buf * WBUF;
     const float* xb = xl + buf * a.xl_floats;
-    auto tap = [&](int j, int dy, int dx) {
+    auto tap = [&](int j, int dy, int dx, int ph) {
       const float* wj = wb + j * CK * WS + aoff;
       const float* xj = xb + (dy * a.IW + dx) * S;
       float av[WM], bv[WN];
@@ -491,17 +495,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
       for (int m = 0; m < WM; ++m)
 #pragma unroll
         for (int b = 0; b < WN; ++b)
-          acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[m][b], 0, 0, 0);
+          acc[ph][m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[ph][m][b], 0, 0, 0);
     };
     if (KIND == KIND_GATHER) {
 #pragma unroll
       for (int j = 0; j < 9; ++j)
-        if (j >= j0 && j < j1) tap(j, (j / 3) * a.dil, (j % 3) * a.dil);
+        if (j >= j0 && j < j1) tap(j, (j / 3) * a.dil, (j % 3) * a.dil, 0);
+    } else if (KIND == KIND_TALL) {
+      // filter tap (ky,kx) of ConvTranspose2d(k3,s2,p1,op1): output row 2y+py takes input row y+dy through ky:
+      // py=0: (dy=0,ky=1); py=1: (dy=0,ky=2),(dy=1,ky=0) -- the same along x.  Nine taps, each into the accumulators of its parity.
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int ky = j / 3, kx = j % 3;
+        const int py = ky == 1 ? 0 : 1, dy = ky == 0 ? 1 : 0, px = kx == 1 ? 0 : 1, dx = kx == 0 ? 1 : 0;
+        if (j >= j0 && j < j1) tap(j, dy, dx, NPH == 4 ? py * 2 + px : 0);
+      }
     } else {
       for (int j = j0; j < j1 && j < ntaps; ++j) {
         const int jy = j / nxt, jx = j - jy * nxt;
-        if (KIND == KIND_TPHASE) tap(j, ti.py ? (jy ? 0 : 1) : 0, ti.px ? (jx ? 0 : 1) : 0);
-        else tap(j, jy, jx);
+        if (KIND == KIND_TPHASE) tap(j, ti.py ? (jy ? 0 : 1) : 0, ti.px ? (jx ? 0 : 1) : 0, 0);
+        else tap(j, jy, jx, 0);
       }
     }
   };
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
     write_x(0, 0);
     if (nchunks > 1) load_x(CK);                     // X(1)
   }
-  const int jsplit = KIND == KIND_GATHER ? 5 : (ntaps + 1) / 2;
+  const int jsplit = (KIND == KIND_GATHER || KIND == KIND_TALL) ? 5 : (ntaps + 1) / 2;
   for (int i = 0; i < nchunks; ++i) {
     const int buf = i & 1;
     // F(i) must have landed; the only younger requests of this wave are the NX loads of X(i+1)
@@ -532,7 +545,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
     }
     if (!dbg_nomfma) taps(buf, jsplit, 9);
   }
-  conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND>(a, ti, acc, red, tid);
+  if (KIND == KIND_TALL) {
+#pragma unroll
+    for (int ph = 0; ph < NPH; ++ph) {
+      TileInfo tp = ti;
+      tp.py = ph >> 1; tp.px = ph & 1;
+      if (ph) __syncthreads();                      // `red` of the previous parity has been consumed
+      conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND_TPHASE>(a, tp, acc[ph], red, tid);
+    }
+  } else {
+    conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND>(a, ti, acc[0], red, tid);
+  }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -681,7 +704,8 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
     if (pl->kind == KIND_TMERGED && cot < pl->CoutP) continue;   // merged layout: all parities in one workgroup
     if (pl->CoutP >= 128 && cot < 64) continue;
     if (pl->CoutP >= 64 && cot < 32) continue;
-    const bool dma_tile = use_dma && (t == 0 || t == 1 || t == 4);
+    const bool tall5 = use_dma && t == 5 && pl->kind == KIND_TPHASE && !getenv("RCV_NO_TALL");     // 32-channel tile: only as KIND_TALL
+    const bool dma_tile = (use_dma && (t == 0 || t == 1 || t == 4)) || tall5;
     const int cap = dma_tile ? kTiles[t].nt() * 4 : 65535;      // DMA variant: input chunk rides in 4 registers per thread
     int R, Wt, tx, ty;
     if (!plan_tile(pl->kind, TH, TW, kTiles[t].pix(), s, d, cap, &R, &Wt, &tx, &ty)) continue;
@@ -691,6 +715,14 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
     }
   }
   RCV_CHECK_ARG(pl->tile >= 0, "conv: no tile configuration for Cout=%d", Cout);
+  if (pl->kind == KIND_TPHASE && use_dma && pl->tile == 2 && !getenv("RCV_NO_TALL")) {
+    // 32-channel transposed conv with >= 64 input channels: the half-size tile runs as KIND_TALL on the LDS-DMA kernel
+    // (64 -> 32 at 32x60x80: 0.100 instead of 0.140 ms)
+    int R, Wt, tx, ty;
+    if (plan_tile(pl->kind, TH, TW, kTiles[5].pix(), s, d, kTiles[5].nt() * 4, &R, &Wt, &tx, &ty)) {
+      pl->tile = 5; pl->R = R; pl->Wt = Wt; pl->tiles_x = tx; pl->tiles_y = ty;
+    }
+  }
   {   // a grid that leaves compute units idle: the sibling tile with the same channel count and half the pixels doubles the
       // workgroups (small planes: 128->64 at 64x15x20 runs 0.068 instead of 0.090 ms)
     const int sibling = (pl->tile == 0 || pl->tile == 1) ? 4 : (pl->tile == 2 ? 5 : (pl->tile == 3 ? 6 : -1));     // 0 -> 4 halves the channels instead
@@ -713,7 +745,8 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   const TileCfg& tc = kTiles[pl->tile];
   tile_halo(pl->kind, pl->R, pl->Wt, s, d, &pl->IH, &pl->IW);
   const int ntaps = pl->kind == KIND_GATHER ? 9 : 4;
-  pl->dma = use_dma && (pl->tile == 0 || pl->tile == 1 || pl->tile == 4) && pl->IH * pl->IW <= tc.nt() * 4;
+  const bool tall5 = pl->tile == 5 && pl->kind == KIND_TPHASE && !getenv("RCV_NO_TALL");
+  pl->dma = use_dma && (pl->tile == 0 || pl->tile == 1 || pl->tile == 4 || tall5) && pl->IH * pl->IW <= tc.nt() * 4;
   size_t floats;
   if (pl->dma) {
     pl->CK = 4;
@@ -731,6 +764,15 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   pl->n_phases = pl->kind == KIND_TPHASE ? 4 : 1;
   const int n_pix_tiles = N * pl->tiles_x * pl->tiles_y;
   pl->total_tiles = n_pix_tiles * pl->n_co_tiles * pl->n_phases;
+  if (pl->kind == KIND_TPHASE && pl->dma && (pl->tile == 4 || pl->tile == 5) && !getenv("RCV_NO_TALL")) {
+    // all four output parities in one workgroup (KIND_TALL): one staging of the input and nine taps per chunk instead of four
+    // workgroups with 1/2/2/4 taps each paying the whole per-chunk overhead; n_phases stays 4: the statistics rows are per parity
+    pl->kind = KIND_TALL;
+    pl->wl_floats = 9 * 4 * tc.cot();
+    floats = 2 * (size_t)pl->wl_floats + 2 * (size_t)pl->xl_floats + 5 * CinP + 16 + (size_t)tc.WAVES_N * 2 * tc.cot();
+    pl->lds = floats * sizeof(float);
+    pl->total_tiles = n_pix_tiles * pl->n_co_tiles;
+  }
   pl->grid = pl->total_tiles;
   return RCV_OK;
 }
@@ -743,7 +785,7 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   const int n_pix_tiles = op->i[RCV_I_N] * pl.tiles_x * pl.tiles_y;
   const int n_part = (pl.narrow || pl.first) ? pl.grid : n_pix_tiles * pl.n_phases;
   if (query) {
-    static const char* kn[] = {"conv", "tconv", "tconvm"};
+    static const char* kn[] = {"conv", "tconv", "tconvm", "tconva"};
     if (pl.first) {
       snprintf(query->label, sizeof(query->label), "conv_first<%d>", op->i[RCV_I_DIL]);
     } else if (pl.narrow) {
@@ -774,7 +816,7 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   a.CinP = round_up(a.Cin, 4); a.CoutP = pl.CoutP; a.CoutV = pl.CoutV;
   a.stride = op->i[RCV_I_STRIDE]; a.dil = op->i[RCV_I_DIL];
   a.R = pl.R; a.Wt = pl.Wt; a.tiles_x = pl.tiles_x; a.tiles_y = pl.tiles_y; a.IH = pl.IH; a.IW = pl.IW;
-  a.n_pix_tiles = n_pix_tiles; a.n_co_tiles = pl.n_co_tiles; a.n_sub = pl.n_co_tiles * pl.n_phases;
+  a.n_pix_tiles = n_pix_tiles; a.n_co_tiles = pl.n_co_tiles; a.n_sub = pl.n_co_tiles * (pl.kind == KIND_TALL ? 1 : pl.n_phases);
   a.total_tiles = pl.total_tiles; a.nchunks = a.CinP / pl.CK;
   a.in_mode = op->i[RCV_I_INMODE]; a.stats = op->i[RCV_I_STATS]; a.flags = op->flags;
   a.wl_floats = pl.wl_floats; a.xl_floats = pl.xl_floats;
@@ -793,6 +835,8 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   if (pl.narrow) return convs_launch(pl, a, a.in_mode == RCV_LOAD_GRAD_ENC || a.in_mode == RCV_LOAD_GRAD_DEC, s);
   const dim3 grid(pl.grid);
   if (pl.dma) {
+    if (pl.kind == KIND_TALL)
+      return pl.tile == 4 ? launch_dma<1, 5, 4, 1, KIND_TALL>(a, grid, pl.lds, s) : launch_dma<1, 5, 2, 2, KIND_TALL>(a, grid, pl.lds, s);
     if (pl.kind == KIND_TPHASE) return launch_dma_tile<KIND_TPHASE>(pl.tile, a, grid, pl.lds, s);
     if (pl.kind == KIND_TMERGED) return launch_dma_tile<KIND_TMERGED>(pl.tile, a, grid, pl.lds, s);
     return launch_dma_tile<KIND_GATHER>(pl.tile, a, grid, pl.lds, s);
