@@ -477,8 +477,6 @@ class Engine:
 
             for node in reversed(nodes):
                 d = node.d
-                if bwd and node_params(node):
-                    pass
                 plan.bwd_marks.append([len(bwd), node])      # patched to (op count after this node, min flat offset) below
                 if node.op == "cls":
                     src = ref(d["src"])
