@@ -273,6 +273,16 @@ int rcv_adam_l1_step(rcv_handle* h, float* param, const float* grad, float* exp_
                      const float* lr_elem /*may be NULL*/, int64_t n, float lr, float beta1, float beta2,
                      float eps, float decay, int step, float grad_scale, void* stream);
 
+/* The same step, which also books the iteration's metrics (train.py:52-53,69-73) in the same launch:
+ * metrics[4] (double, device) += { loss_stats[0] + decay*sum|p|, decay*sum|p|, loss_stats[2], 1 } with sum|p| taken before
+ * the update (the reference's l1reg(model)); loss_stats = the float row the loss op wrote ([0] loss, [2] #correct pixels).
+ * workspace: rcv_op_workspace bytes of an RCV_OP_ADAM_L1 op with the same n (zero-filled once; the launch leaves its ticket
+ * zero); workspace_rows = the op's i[RCV_I_NPART].  As an op: p[RCV_P_X3] = metrics, p[RCV_P_X4] = loss_stats, p[RCV_P_PART]. */
+int rcv_adam_l1_step_metrics(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                             const float* lr_elem /*may be NULL*/, int64_t n, float lr, float beta1, float beta2,
+                             float eps, float decay, int step, float grad_scale, double* metrics, const float* loss_stats,
+                             void* workspace, int workspace_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,7 +43,7 @@ EXPORTS = [
     "rcv_create", "rcv_destroy", "rcv_last_error", "rcv_version", "rcv_num_cus", "rcv_op_workspace", "rcv_run",
     "rcv_run_timed", "rcv_op_kernel_label", "rcv_run_ex", "rcv_join_side",
     "rcv_conv3x3", "rcv_convT3x3s2", "rcv_wgrad3x3", "rcv_bn_finalize", "rcv_bn_backward", "rcv_maxpool2x2_fwd",
-    "rcv_softmax_ce_argmax_fwd", "rcv_softmax_ce_bwd", "rcv_adam_l1_step", "rcv_confusion",
+    "rcv_softmax_ce_argmax_fwd", "rcv_softmax_ce_bwd", "rcv_adam_l1_step", "rcv_adam_l1_step_metrics", "rcv_confusion",
     "rcv_dice_fwd", "rcv_dice_bwd", "rcv_sgd_step",
 ]
 

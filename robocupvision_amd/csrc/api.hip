@@ -308,4 +308,19 @@ int rcv_adam_l1_step(rcv_handle* h, float* param, const float* grad, float* exp_
   return rcv_run(h, &op, 1, stream);
 }
 
+int rcv_adam_l1_step_metrics(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* lr_elem,
+                             int64_t n, float lr, float beta1, float beta2, float eps, float decay, int step, float grad_scale,
+                             double* metrics, const float* loss_stats, void* workspace, int workspace_rows, void* stream) {
+  RCV_CHECK_ARG(n > 0 && n < 2147483647LL, "rcv_adam_l1_step_metrics: n out of range");
+  RCV_CHECK_ARG(metrics && loss_stats && workspace, "rcv_adam_l1_step_metrics: null operand");
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_ADAM_L1;
+  op.i[RCV_I_COUNT] = (int)n; op.i[RCV_I_AUX0] = step; op.i[RCV_I_NPART] = workspace_rows;
+  op.f[0] = lr; op.f[1] = beta1; op.f[2] = beta2; op.f[3] = eps; op.f[4] = decay; op.f[5] = grad_scale;
+  op.p[RCV_P_IN] = param; op.p[RCV_P_IN2] = (void*)grad; op.p[RCV_P_X0] = exp_avg; op.p[RCV_P_X1] = exp_avg_sq;
+  op.p[RCV_P_X2] = (void*)lr_elem; op.p[RCV_P_X3] = metrics; op.p[RCV_P_X4] = (void*)loss_stats; op.p[RCV_P_PART] = workspace;
+  return rcv_run(h, &op, 1, stream);
+}
+
 }  // extern "C"

@@ -746,11 +746,19 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dp, const float* __res
 // gradient of decay*sum|p|, train.py:23-27,53-55) followed by torch.optim.Adam's update
 // (train.py:67, defaults betas .9/.999 eps 1e-8, no weight decay, no amsgrad).
 // ------------------------------------------------------------------------------------------
+// MET: the launch also books the step's metrics (train.py:52-53,69-73: loss = CE + decay*sum|p|, reg, #correct pixels): every
+// workgroup leaves its sum of |p| (taken BEFORE the update, as the reference's l1reg(model) is) in `part`, the workgroup that
+// finishes last adds the rows in index order and updates metrics[4] = {sum loss, sum reg, sum #correct, steps} in double.
+// part = double[gridDim.x] followed by one uint32 ticket counter (zero before the first launch; left zero by every launch).
+template <bool MET>
 __global__ void adam_l1_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                const float* __restrict__ lr_elem, size_t n, float lr, float b1, float b2, float eps, float decay,
-                               float grad_scale, float bc1, float bc2_sqrt) {
+                               float grad_scale, float bc1, float bc2_sqrt, double* part, const float* __restrict__ loss_stats,
+                               double* metrics) {
+  float asum = 0.f;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
     const float pv = p[e];
+    if (MET) asum += fabsf(pv);
     const float sg = pv > 0.f ? 1.f : (pv < 0.f ? -1.f : 0.f);
     const float gr = fmaf(decay, sg, g[e] * grad_scale);
     const float mm = b1 * m[e] + (1.f - b1) * gr;
@@ -759,6 +767,34 @@ __global__ void adam_l1_kernel(float* __restrict__ p, const float* __restrict__ 
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
     const float step = (lr_elem ? lr_elem[e] : lr) / bc1;
     p[e] = pv - step * (mm / denom);
+  }
+  if (MET) {
+    __shared__ int is_last;
+    unsigned* ticket = reinterpret_cast<unsigned*>(part + gridDim.x);
+    double a = (double)asum, dummy = 0.0;
+    block_sum2_d(a, dummy);
+    if (threadIdx.x == 0) {
+      part[blockIdx.x] = a;
+      __threadfence();                                   // the row is visible device-wide before the ticket is taken
+      is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (is_last) {
+      __threadfence();
+      double s = 0.0;
+      for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) s += __builtin_nontemporal_load(part + i);
+      dummy = 0.0;
+      __syncthreads();                                   // block_sum2_d's scratch is reused
+      block_sum2_d(s, dummy);
+      if (threadIdx.x == 0) {
+        const double reg = (double)decay * s;
+        metrics[0] += (double)loss_stats[0] + reg;
+        metrics[1] += reg;
+        metrics[2] += (double)loss_stats[2];
+        metrics[3] += 1.0;
+        *ticket = 0u;
+      }
+    }
   }
 }
 
@@ -1097,16 +1133,29 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       break;
     }
     case RCV_OP_ADAM_L1: {
-      if (query) return RCV_OK;
       const size_t n = (size_t)(uint32_t)op->i[RCV_I_COUNT];
+      if (query) {                                       // workspace of the metrics variant: one double per workgroup + the ticket
+        query->n_part = stream_grid(h, n, 256);
+        query->part_bytes = ((size_t)query->n_part + 1) * sizeof(double);
+        return RCV_OK;
+      }
       const int step = op->i[RCV_I_AUX0];
       RCV_CHECK_ARG(n > 0 && step >= 1 && op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_X0] && op->p[RCV_P_X1], "adam: bad operand");
       const float b1 = op->f[1], b2 = op->f[2];
       const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
       const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)step));
-      hipLaunchKernelGGL(adam_l1_kernel, dim3(stream_grid(h, n, 256)), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
-                         (float*)op->p[RCV_P_X0], (float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], n, op->f[0], b1, b2, op->f[3],
-                         op->f[4], op->f[5], bc1, bc2s);
+      const int g = stream_grid(h, n, 256);
+      double* part = (double*)op->p[RCV_P_PART];
+      if (op->p[RCV_P_X3]) {
+        RCV_CHECK_ARG(part && op->p[RCV_P_X4] && op->i[RCV_I_NPART] == g, "adam + metrics: needs loss stats and a %d-row workspace (rcv_op_workspace)", g);
+        hipLaunchKernelGGL(adam_l1_kernel<true>, dim3(g), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
+                           (float*)op->p[RCV_P_X0], (float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], n, op->f[0], b1, b2, op->f[3],
+                           op->f[4], op->f[5], bc1, bc2s, part, (const float*)op->p[RCV_P_X4], (double*)op->p[RCV_P_X3]);
+      } else {
+        hipLaunchKernelGGL(adam_l1_kernel<false>, dim3(g), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
+                           (float*)op->p[RCV_P_X0], (float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], n, op->f[0], b1, b2, op->f[3],
+                           op->f[4], op->f[5], bc1, bc2s, (double*)nullptr, (const float*)nullptr, (double*)nullptr);
+      }
       break;
     }
     case RCV_OP_SGD: {

@@ -39,6 +39,7 @@ class AdamL1(torch.optim.Optimizer):
         self._t = 0
         self._lr_elem = None
         self._lr_key = None
+        self._met_ws: Optional[torch.Tensor] = None
         super().__init__(reference_param_groups(model, lr, transfer), dict(lr=lr, betas=betas, eps=eps))
 
     def _flat(self):
@@ -48,7 +49,9 @@ class AdamL1(torch.optim.Optimizer):
         return eng, eng.flat
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, metrics: Optional[torch.Tensor] = None, loss_stats: Optional[torch.Tensor] = None):
+        """``metrics`` (float64[4], device) and ``loss_stats`` (the float row the loss wrote: [0] loss, [2] #correct pixels):
+        the same launch also adds {loss + decay*sum|p|, decay*sum|p|, #correct, 1} to ``metrics`` (train.py:52-53,69-73)."""
         eng, fl = self._flat()
         if self._m is None or self._m.numel() != fl.numel or self._m.device != fl.data.device:
             self._m = torch.zeros_like(fl.data)
@@ -77,6 +80,14 @@ class AdamL1(torch.optim.Optimizer):
         op = L.make_op(L.OP_ADAM_L1, 0, count=fl.numel, aux0=self._t, f0=lrs[0][0], f1=b1, f2=b2, f3=self.defaults["eps"],
                        f4=self.decay, f5=self.grad_scale, p_in=fl.data.data_ptr(), p_in2=fl.grad.data_ptr(),
                        p_x0=self._m.data_ptr(), p_x1=self._v.data_ptr(), p_x2=lr_elem_ptr)
+        if metrics is not None:
+            if loss_stats is None or metrics.dtype != torch.float64 or metrics.numel() < 4 or loss_stats.dtype != torch.float32 \
+                    or loss_stats.numel() < 3 or not metrics.is_cuda or not loss_stats.is_cuda:
+                raise L.RcvError("AdamL1.step(metrics=...): needs a float64[4] device tensor and the loss op's float stats row")
+            nbytes = L.op_workspace(eng.handle, op)                  # fills op.i[NPART]
+            if self._met_ws is None or self._met_ws.numel() * 8 < nbytes or self._met_ws.device != fl.data.device:
+                self._met_ws = torch.zeros((nbytes + 7) // 8, dtype=torch.float64, device=fl.data.device)
+            op.p[L.RCV_P_X3], op.p[L.RCV_P_X4], op.p[L.RCV_P_PART] = metrics.data_ptr(), loss_stats.data_ptr(), self._met_ws.data_ptr()
         L.OpList([op]).run(eng.handle, torch.cuda.current_stream(fl.data.device).cuda_stream)
 
     def l1_term(self) -> torch.Tensor:

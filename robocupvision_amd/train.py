@@ -110,13 +110,18 @@ class Trainer:
             pred = model(imgs)
             ce = crit(pred, targets)
             ce.backward()
-        with torch.no_grad():
-            reg = opt.l1_term() if hasattr(opt, "l1_term") else torch.zeros((), device=self.device)
-            self.metrics += torch.stack([ce.detach().double() + reg.double(), reg.double(),
-                                         crit.last_stats[2].double(), torch.ones((), dtype=torch.float64, device=self.device)])
         if self._pending is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._pending)
-        opt.step()
+        if isinstance(opt, AdamL1):
+            # loss + decay*sum|p|, reg, #correct and the step count are booked by the optimizer launch itself (the parameters
+            # it reads are the pre-update ones the reference's l1reg(model) sees): no per-step torch reductions
+            opt.step(metrics=self.metrics, loss_stats=crit.last_stats)
+        else:
+            with torch.no_grad():
+                reg = opt.l1_term() if hasattr(opt, "l1_term") else torch.zeros((), device=self.device)
+                self.metrics += torch.stack([ce.detach().double() + reg.double(), reg.double(),
+                                             crit.last_stats[2].double(), torch.ones((), dtype=torch.float64, device=self.device)])
+            opt.step()
         return pred
 
     @torch.no_grad()

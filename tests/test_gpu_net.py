@@ -257,6 +257,40 @@ def test_trainer_fused_step_vs_golden(golden, tag):
     assert tr.pop_metrics()["loss"] < m["loss"]
 
 
+def test_trainer_metrics_in_optimizer_launch(golden):
+    """The Adam launch books loss / reg / #correct / steps itself (one workgroup ticket per launch); over several steps it
+    must agree with the bookkeeping done with separate reductions (decay*sum|p| BEFORE each update, the loss row, a count)."""
+    from robocupvision_amd.train import Trainer
+    tag = "robo_s_2x48x64"
+    net_kats, m = golden(tag)
+    model = build(m["ctor"]).to(DEV)
+    tr = Trainer(model, class_weights=CE_W, lr=1e-3, decay=1e-4)
+    x, t = _t(net_kats[tag + "/x"]).to(DEV), _t(net_kats[tag + "/t"]).to(DEV)
+    exp = [0.0, 0.0, 0.0]
+    for it in range(4):
+        if it:
+            exp[1] += float(tr.optimizer.l1_term())      # parameters the coming step's update starts from
+        tr.step(x, t)
+        if it == 0:
+            continue                                     # (the flat buffer exists only after the first forward)
+        st = tr.criterion.last_stats
+        exp[0] += float(st[0]); exp[2] += float(st[2])
+    first = tr.pop_metrics()
+    assert first["steps"] == 4
+    tr.step(x, t)
+    assert tr.pop_metrics()["steps"] == 1                # the ticket was left at zero
+    # steps 2..4 against the separately reduced values (step 1 is pinned by test_trainer_fused_step_vs_golden)
+    model2 = build(m["ctor"]).to(DEV)
+    tr2 = Trainer(model2, class_weights=CE_W, lr=1e-3, decay=1e-4)
+    tr2.step(x, t)
+    one = tr2.pop_metrics()
+    got_reg = first["reg"] * 4 - one["reg"]
+    got_loss = first["loss"] * 4 - one["loss"]
+    assert abs(got_reg - exp[1]) <= 1e-5 * abs(exp[1]), (got_reg, exp[1])
+    assert abs(got_loss - (exp[0] + exp[1])) <= 1e-5 * abs(exp[0] + exp[1]), (got_loss, exp[0] + exp[1])
+    assert first["correct_pixels"] - one["correct_pixels"] == exp[2]
+
+
 def test_labelprop_inference_vs_golden():
     """BASELINE config 5: LabelProp frame-pair inference (model.py:538-567) against the reference's output for
     seeded weights and an 8-channel input built with the labelPropTrain.py:178-182 recipe."""
