@@ -1,0 +1,184 @@
+// Filter gradient of the first layer (model.py:475 Level0.Conv0, 3 -> 8 channels on the NCHW image; PB_FCN's dilated conv0) on the
+// vector ALU.
+//
+//   dW[cb][ci][ky][kx] = sum_p dz[p][cb] * img[ci][p + (ky,kx)*d - d]        db[cb] = sum_p dz[p][cb]
+//
+// 27 x 8 outputs from 19 floats per pixel (3 image planes, r and dy of the 8-channel output): 0.75 GB of HBM traffic and 2.1 GFMA at
+// 32 x 480 x 640.  In the MFMA formulation (k = pixels, n = (tap, ci) folded into two 16-column blocks) the matrix unit is 80 % idle
+// and the kernel is a chain of staging latencies (1.96 TB/s measured).  Here the contraction runs as plain FMAs, with the fp32
+// vector rate of gfx950 equal to its fp32 MFMA rate:
+//   * a workgroup is six waves, one per (image channel, half of the output channels); a lane owns one pixel column of an 8 x 64 tile
+//     and walks its 8 rows, keeping 9 taps x 4 output channels in 36 registers ACROSS all tiles of the (persistent) workgroup;
+//   * dz = BN/ReLU backward applied while staging (RCV_LOAD_GRAD_*), written once to LDS as [pixel][8]; the image tile (with halo)
+//     plane by plane; a lane reads 16 B of dz and 9 image values per pixel for 36 FMAs, every LDS access lane-contiguous;
+//   * 24 KB of LDS, 106 registers: two workgroups (12 waves) per CU overlap their staging and arithmetic phases;
+//   * at the end every wave sums its 36 accumulators over the lanes (fixed butterfly) and writes ONE partial row in the layout
+//     RCV_OP_WGRAD_REDUCE sums ([split][tap][cb][ca]), the two waves of image channel 0 also the bias row -- no atomics, bitwise reproducible.
+#include <stdlib.h>
+#include "wgrad_common.h"
+
+__device__ __forceinline__ float wf_wave_sum(float v) {
+#pragma unroll
+  for (int sh = 32; sh >= 1; sh >>= 1) v += __shfl_xor(v, sh);
+  return v;
+}
+
+template <int DIL>
+__global__ __launch_bounds__(384) void wgrad_first_kernel(const WgradArgs a, int tiles_x, int tiles_y, int total_tiles) {
+  constexpr int TY = 8, TX = 64, NT = 384;
+  constexpr int IH = TY + 2 * DIL, IW = TX + 2 * DIL;
+  __shared__ float4 dzs[TY * TX * 2];          // [pixel][2 quads]
+  __shared__ float xs[3 * IH * IW];            // [ci][row][col]
+  __shared__ float4 kc[2 * 5];                 // load constants of the two channel quads
+  const int tid = threadIdx.x, lane = tid & 63, ci = tid >> 7, half = (tid >> 6) & 1;
+  const int split = blockIdx.x;
+  const bool p_two = a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC;
+  const size_t plane = (size_t)a.H * a.W;
+
+  if (tid < 10) kc[tid] = a.p_mode != RCV_LOAD_PLAIN ? wld4(a.p_c + (size_t)(tid % 5) * a.CB + 4 * (tid / 5)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
+  float bs[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bs[c] = 0.f;
+
+  // (A register-prefetch pipeline -- loads of tile i+1 issued branch-free before the arithmetic of tile i -- was measured: 0.246 vs
+  // 0.251 ms at 32x480x640 and slower on small planes; what bounds the kernel is the number of bytes in flight per CU.)
+  for (int tile = split; tile < total_tiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx_i = t % tiles_x; t /= tiles_x;
+    const int ty_i = t % tiles_y;
+    const int n = t / tiles_y;
+    const int y0 = ty_i * TY, x0 = tx_i * TX;
+    __syncthreads();                                      // the previous tile is consumed
+    {   // ---- dz tile: thread -> quad (tid & 1) of pixels tid/2 + 192*u; 6 independent 16-byte loads in flight
+      const int q = tid & 1;
+      constexpr int UNR = 3;                              // 3 * 192 = 576 >= 512 pixels
+      float4 x[UNR], ax[UNR];
+      bool ok[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int pix = (tid >> 1) + u * (NT / 2);
+        const int iy = pix >> 6, ix = pix & 63;
+        const int gy = y0 + iy, gx = x0 + ix;
+        ok[u] = pix < TY * TX && gy < a.Hp && gx < a.Wp;
+        x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ax[u] = x[u];
+        if (ok[u]) {
+          const size_t off = ((size_t)(n * a.Hp + gy) * a.Wp + gx) * a.CB + 4 * q;
+          x[u] = wld4(a.p + off);
+          if (p_two) ax[u] = wld4(a.p_aux + off);
+        }
+      }
+      float4 k[5];                                        // from LDS, behind the tile loads: not live while those are in flight
+#pragma unroll
+      for (int j = 0; j < 5; ++j) k[j] = kc[q * 5 + j];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int pix = (tid >> 1) + u * (NT / 2);
+        if (pix < TY * TX) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok[u]) v = wxform_rt(a.p_mode, x[u], ax[u], k);
+          dzs[pix * 2 + q] = v;
+        }
+      }
+    }
+    {   // ---- image tile: CA planes of IH x IW with zero padding, coalesced row reads, 4 loads in flight
+      const int per_plane = IH * IW, total = a.CA * per_plane;
+      for (int e0 = tid; e0 < total; e0 += 4 * NT) {
+        float v[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * NT;
+          v[u] = 0.f; dst[u] = -1;
+          if (e < total) {
+            const int c = e / per_plane, r = e - c * per_plane;
+            const int iy = r / IW, ix = r - iy * IW;
+            const int gy = y0 - DIL + iy, gx = x0 - DIL + ix;
+            dst[u] = e;
+            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) v[u] = a.g[((size_t)n * a.CA + c) * plane + (size_t)gy * a.W + gx];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (dst[u] >= 0) xs[dst[u]] = v[u];
+      }
+    }
+    __syncthreads();
+    if (ci < a.CA) {
+      const float* xc = xs + ci * IH * IW + lane;
+#pragma unroll 2
+      for (int j = 0; j < TY; ++j) {
+        const float4 d0 = dzs[(j * TX + lane) * 2 + half];
+        const float dz[4] = {d0.x, d0.y, d0.z, d0.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bs[c] += dz[c];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float xv = xc[(j + ky * DIL) * IW + kx * DIL];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[ky * 3 + kx][c] = fmaf(xv, dz[c], acc[ky * 3 + kx][c]);
+          }
+      }
+    }
+  }
+
+  // ---- one partial row per workgroup
+  if (ci < a.CA) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float u = wf_wave_sum(acc[t][c]);
+        if (lane == 0) a.part[(((size_t)split * 9 + t) * a.CBP + 4 * half + c) * a.CAP + ci] = u;
+      }
+  }
+  if (ci == 0 && a.part_bias) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float u = wf_wave_sum(bs[c]);
+      if (lane == 0) a.part_bias[(size_t)split * a.CBP + 4 * half + c] = u;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------------
+bool wgrad_first_supported(const rcv_op* op) {
+  if (getenv("RCV_NO_WGRAD_FIRST")) return false;
+  const int d = op->i[RCV_I_DIL];
+  return op->i[RCV_I_INMODE] == RCV_LOAD_NCHW && op->i[RCV_I_CIN] <= 3 && op->i[RCV_I_COUT] == 8 && op->i[RCV_I_STRIDE] == 1 &&
+         (d == 1 || d == 2) && op->i[RCV_I_INMODE2] != RCV_LOAD_NCHW;
+}
+
+static inline int wf_occ() { return 2; }   // two workgroups of six waves per CU (106 registers; a third one needs <= 96 and spilled: slower)
+
+static inline int wf_tiles(const rcv_op* op, int* tx, int* ty) {
+  *tx = ceil_div(op->i[RCV_I_WO], 64); *ty = ceil_div(op->i[RCV_I_HO], 8);
+  return op->i[RCV_I_N] * *tx * *ty;
+}
+
+int wgrad_first_nsplit(const rcv_handle* h, const rcv_op* op) {
+  int tx, ty;
+  const int ntiles = wf_tiles(op, &tx, &ty);
+  int nsplit = h->num_cus * wf_occ();                // persistent workgroups of six waves (24 KB of LDS each)
+  if (nsplit > ntiles) nsplit = ntiles;
+  return ceil_div(ntiles, ceil_div(ntiles, nsplit)); // equal tile counts per workgroup
+}
+
+int wgrad_first_launch(const rcv_handle* h, const WgradArgs& a, hipStream_t s) {
+  const int tiles_x = ceil_div(a.Wp, 64), tiles_y = ceil_div(a.Hp, 8);
+  const int total = a.N * tiles_x * tiles_y;
+  (void)h;
+  const dim3 g(a.nsplit), b(384);
+  if (a.dil == 1) hipLaunchKernelGGL((wgrad_first_kernel<1>), g, b, 0, s, a, tiles_x, tiles_y, total);
+  else hipLaunchKernelGGL((wgrad_first_kernel<2>), g, b, 0, s, a, tiles_x, tiles_y, total);
+  RCV_HIP(hipGetLastError());
+  return RCV_OK;
+}

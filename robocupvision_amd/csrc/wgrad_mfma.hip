@@ -21,61 +21,7 @@
 // time: two co-resident workgroups run in lockstep and overlap nothing.)  Workgroups write partial filters
 // [split][tap][cb][ca] that RCV_OP_WGRAD_REDUCE sums in a fixed order (no float atomics => bitwise reproducible).
 #include <stdlib.h>
-#include "rcv_internal.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct WgradArgs {
-  const float* g; const float* g_aux; const float* g_c;
-  const float* p; const float* p_aux; const float* p_c;
-  float* part;        // [nsplit][9][CBP][CAP]
-  float* part_bias;   // [nsplit][CBP] or null
-  int g_mode, p_mode;
-  int N, H, W, Hp, Wp, CA, CB, CAP, CBP;
-  int stride, dil;
-  int R, Wt, Wt4, tiles_x, tiles_y, ntiles, IH, IW, SP, SG;
-  int nsplit, nctiles;
-  uint32_t dbg;
-  int pl_floats, gl_floats;      // LDS carve: P tile, G tile (then the load constants)
-  FastDiv fdWt4, fdIW;
-};
-
-__device__ __forceinline__ float4 wld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-template <int MODE>
-__device__ __forceinline__ float4 wxform4(float4 x, float4 a, const float4 (&k)[5]) {
-  float4 v;
-  if (MODE == RCV_LOAD_PLAIN || MODE == RCV_LOAD_NCHW) {
-    v = x;
-  } else if (MODE == RCV_LOAD_AFFINE) {
-    v.x = fmaf(x.x, k[0].x, k[1].x); v.y = fmaf(x.y, k[0].y, k[1].y);
-    v.z = fmaf(x.z, k[0].z, k[1].z); v.w = fmaf(x.w, k[0].w, k[1].w);
-  } else if (MODE == RCV_LOAD_AFFINE_RELU) {
-    v.x = fmaxf(fmaf(x.x, k[0].x, k[1].x), 0.f); v.y = fmaxf(fmaf(x.y, k[0].y, k[1].y), 0.f);
-    v.z = fmaxf(fmaf(x.z, k[0].z, k[1].z), 0.f); v.w = fmaxf(fmaf(x.w, k[0].w, k[1].w), 0.f);
-  } else if (MODE == RCV_LOAD_GRAD_ENC) {
-    v.x = a.x > 0.f ? fmaf(k[0].x, x.x, fmaf(k[2].x, a.x, k[1].x)) : 0.f;
-    v.y = a.y > 0.f ? fmaf(k[0].y, x.y, fmaf(k[2].y, a.y, k[1].y)) : 0.f;
-    v.z = a.z > 0.f ? fmaf(k[0].z, x.z, fmaf(k[2].z, a.z, k[1].z)) : 0.f;
-    v.w = a.w > 0.f ? fmaf(k[0].w, x.w, fmaf(k[2].w, a.w, k[1].w)) : 0.f;
-  } else {
-    v.x = fmaf(k[0].x, (fmaf(a.x, k[3].x, k[4].x) > 0.f ? x.x : 0.f), fmaf(k[2].x, a.x, k[1].x));
-    v.y = fmaf(k[0].y, (fmaf(a.y, k[3].y, k[4].y) > 0.f ? x.y : 0.f), fmaf(k[2].y, a.y, k[1].y));
-    v.z = fmaf(k[0].z, (fmaf(a.z, k[3].z, k[4].z) > 0.f ? x.z : 0.f), fmaf(k[2].z, a.z, k[1].z));
-    v.w = fmaf(k[0].w, (fmaf(a.w, k[3].w, k[4].w) > 0.f ? x.w : 0.f), fmaf(k[2].w, a.w, k[1].w));
-  }
-  return v;
-}
-
-__device__ __forceinline__ float4 wxform_rt(int mode, float4 x, float4 a, const float4 (&k)[5]) {
-  switch (mode) {
-    case RCV_LOAD_PLAIN: case RCV_LOAD_NCHW: return x;
-    case RCV_LOAD_AFFINE: return wxform4<RCV_LOAD_AFFINE>(x, a, k);
-    case RCV_LOAD_AFFINE_RELU: return wxform4<RCV_LOAD_AFFINE_RELU>(x, a, k);
-    case RCV_LOAD_GRAD_ENC: return wxform4<RCV_LOAD_GRAD_ENC>(x, a, k);
-    default: return wxform4<RCV_LOAD_GRAD_DEC>(x, a, k);
-  }
-}
+#include "wgrad_common.h"
 
 // NBF == 0: regular mode (WN column blocks of 16 gathered channels, 9 taps each)
 // NBF  > 0: folded mode (WN must be 1): NBF column blocks over n = tap*CA + ca
@@ -480,7 +426,7 @@ static int wlaunch_inst(const WgradArgs& a, bool gtwo, dim3 grid, size_t lds, hi
   return RCV_OK;
 }
 
-struct WPlan { int nctiles; int tile; int R, Wt, Wt4, tiles_x, tiles_y, IH, IW, SP, SG, nsplit, pl_floats, gl_floats; size_t lds; dim3 grid; int CAP, CBP; };
+struct WPlan { int first; int nctiles; int tile; int R, Wt, Wt4, tiles_x, tiles_y, IH, IW, SP, SG, nsplit, pl_floats, gl_floats; size_t lds; dim3 grid; int CAP, CBP; };
 
 static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   const int N = op->i[RCV_I_N], H = op->i[RCV_I_H], W = op->i[RCV_I_W];
@@ -494,10 +440,19 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   const bool nchw = op->i[RCV_I_INMODE] == RCV_LOAD_NCHW;
   if (nchw) RCV_CHECK_ARG(CA <= 4, "wgrad: NCHW gathered operand supports <=4 channels");
   else RCV_CHECK_ARG(CA % 4 == 0, "wgrad: gathered channels %d must be a multiple of 4", CA);
-  pl->CAP = round_up(CA, 16); pl->CBP = round_up(CB, 16);
+  pl->CAP = wgrad_cap(CA); pl->CBP = round_up(CB, 16);
   const int cbt_want = pl->CBP >= 64 ? 64 : (pl->CBP >= 32 ? 32 : 16);
   const int cat_want = pl->CAP >= 64 ? 64 : (pl->CAP >= 32 ? 32 : 16);
   pl->tile = -1;
+  pl->first = 0;
+  if (wgrad_first_supported(op)) {      // first layer: vector-ALU kernel (wgrad_first.hip), one partial row per persistent workgroup
+    pl->first = 1;
+    pl->nsplit = wgrad_first_nsplit(h, op);
+    pl->nctiles = 1; pl->lds = 0; pl->grid = dim3(pl->nsplit, 1, 1);
+    pl->R = 8; pl->Wt = 64; pl->Wt4 = 64; pl->tiles_x = ceil_div(Wp, 64); pl->tiles_y = ceil_div(Hp, 8);
+    pl->IH = 8 + 2 * d; pl->IW = 64 + 2 * d; pl->SP = 8; pl->SG = 1; pl->pl_floats = 0; pl->gl_floats = 0;
+    return RCV_OK;
+  }
   const bool fold = CA <= 8 && cbt_want == 16 && !getenv("RCV_NO_FOLD");
   if (fold) pl->tile = 9 * CA <= 32 ? 7 : 8;
   else {
@@ -563,7 +518,7 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   if (op->kind == RCV_OP_WGRAD_REDUCE) {
     if (query) { snprintf(query->label, sizeof(query->label), "wgrad_reduce"); query->n_part = 0; query->n_split = 0; query->part_bytes = 0; return RCV_OK; }
     const int CA = op->i[RCV_I_CIN], CB = op->i[RCV_I_COUT], nsplit = op->i[RCV_I_NSPLIT];
-    const int CAP = round_up(CA, 16), CBP = round_up(CB, 16);
+    const int CAP = wgrad_cap(CA), CBP = round_up(CB, 16);
     const float* part = (const float*)op->p[RCV_P_PART];
     float* dw = (float*)op->p[RCV_P_OUT];
     float* db = (float*)op->p[RCV_P_BIAS];
@@ -577,6 +532,13 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   WPlan pl;
   int rc = wmake_plan(h, op, &pl);
   if (rc) return rc;
+  if (query && pl.first) {
+    snprintf(query->label, sizeof(query->label), "wgrad_first<%d>", op->i[RCV_I_DIL]);
+    query->n_part = 0;
+    query->n_split = pl.nsplit;
+    query->part_bytes = (size_t)pl.nsplit * (9 * (size_t)pl.CBP * pl.CAP + pl.CBP) * sizeof(float);
+    return RCV_OK;
+  }
   if (query) {
     const WTile& wt = kWT[pl.tile];
     snprintf(query->label, sizeof(query->label), "wgrad_mfma<%d,%d,%d,%d,%d,f%d>", wt.WM, wt.WN, wt.WAVES_M, wt.WAVES_N, wt.WAVES_K, wt.NBF);
@@ -608,6 +570,7 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   RCV_CHECK_ARG(!g_two || a.g_aux, "wgrad: gathered gradient load needs aux");
   RCV_CHECK_ARG(!p_two || a.p_aux, "wgrad: pointwise gradient load needs aux");
   a.part_bias = (op->flags & RCV_F_BIAS) ? a.part + (size_t)pl.nsplit * 9 * pl.CBP * pl.CAP : nullptr;
+  if (pl.first) return wgrad_first_launch(h, a, s);
   switch (pl.tile) {
     case 0: return wlaunch_inst<2, 2, 2, 2, 1, 0, true>(a, g_two, pl.grid, pl.lds, s);
     case 1: return wlaunch_inst<2, 2, 2, 1, 2, 0, true>(a, g_two, pl.grid, pl.lds, s);

@@ -150,3 +150,55 @@ def test_device_metrics_match_reference_loops():
     out = m.compute()
     assert abs(out["mean_class_acc"] - ref_cls) < 1e-4 and abs(out["mean_iou"] - ref_iou) < 1e-4      # the loop reference is fp32
     assert abs(out["pixel_acc"] - float((pred == tgt).sum()) / pred.numel() * 100) < 1e-9
+
+
+@pytest.mark.parametrize("N,H,W,dil,mode2", [(2, 37, 70, 1, "grad_enc"), (1, 19, 131, 2, "grad_dec"), (3, 8, 64, 1, "plain"),
+                                              (2, 40, 129, 2, "grad_enc")])
+def test_first_layer_filter_gradient_kernels(N, H, W, dil, mode2, monkeypatch):
+    """RCV_OP_WGRAD on the NCHW image (3 -> 8 channels: model.py:475 Level0.Conv0, PB_FCN's dilated conv0) through the C ABI: the
+    vector-ALU kernel (wgrad_first.hip) and the matrix-core kernel it replaces on this layer, both against the float64 filter
+    gradient of torch's conv2d for ragged planes; tolerance 2e-5 of the largest entry (fp32 sums over N*H*W pixels)."""
+    from robocupvision_amd import _lib as L
+    dev = torch.device("cuda:0")
+    h = L.handle(0)
+    g = torch.Generator().manual_seed(7)
+    img = torch.randn(N, 3, H, W, generator=g)
+    gy = torch.randn(N, H, W, 8, generator=g)                     # gradient at the block output (NHWC)
+    r = torch.randn(N, H, W, 8, generator=g)                      # the stored relu(conv) / raw conv output
+    k = torch.rand(5, 8, generator=g) + 0.5
+    k64, gy64, r64 = k.double(), gy.double(), r.double()
+    if mode2 == "plain":
+        dz = gy64
+    elif mode2 == "grad_enc":                                     # dz = r > 0 ? k0*g + k2*r + k1 : 0      (include/rcv.h RCV_LOAD_GRAD_ENC)
+        dz = torch.where(r64 > 0, k64[0] * gy64 + k64[2] * r64 + k64[1], torch.zeros_like(r64))
+    else:                                                         # dz = k0*(k3*r + k4 > 0 ? g : 0) + k2*r + k1  (RCV_LOAD_GRAD_DEC)
+        dz = k64[0] * torch.where(k64[3] * r64 + k64[4] > 0, gy64, torch.zeros_like(gy64)) + k64[2] * r64 + k64[1]
+    w = torch.zeros(8, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(8, dtype=torch.float64, requires_grad=True)
+    out = torch.nn.functional.conv2d(img.double(), w, b, stride=1, padding=dil, dilation=dil)
+    out.backward(dz.permute(0, 3, 1, 2))
+    modes = {"plain": L.LOAD_PLAIN, "grad_enc": L.LOAD_GRAD_ENC, "grad_dec": L.LOAD_GRAD_DEC}
+    img_d, gy_d, r_d, k_d = img.to(dev), gy.to(dev), r.to(dev), k.to(dev)
+    labels = []
+    for no_first in (False, True):
+        if no_first:
+            monkeypatch.setenv("RCV_NO_WGRAD_FIRST", "1")
+        else:
+            monkeypatch.delenv("RCV_NO_WGRAD_FIRST", raising=False)
+        dw = torch.full((8, 3, 3, 3), float("nan"), device=dev)
+        db = torch.full((8,), float("nan"), device=dev)
+        op = L.make_op(L.OP_WGRAD, L.F_BIAS, n=N, h=H, w=W, cin=3, ho=H, wo=W, cout=8, stride=1, dil=dil, inmode=L.LOAD_NCHW,
+                       inmode2=modes[mode2], p_in=img_d.data_ptr(), p_in2=gy_d.data_ptr(), p_in2_aux=r_d.data_ptr(), p_in2_c=k_d.data_ptr())
+        nb = L.op_workspace(h, op)
+        part = torch.full((max(nb // 4, 4),), float("nan"), device=dev)   # rows no workgroup writes must not be read into results
+        op.p[L.RCV_P_PART] = part.data_ptr()
+        red = L.make_op(L.OP_WGRAD_REDUCE, 0, cin=3, cout=8, nsplit=op.i[L.RCV_I_NSPLIT], p_part=part.data_ptr(), p_out=dw.data_ptr(),
+                        p_bias=db.data_ptr())
+        lst = L.OpList([op, red])
+        labels.append(lst.labels(h)[0])
+        lst.run(h, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for got, ref, what in ((dw, w.grad, "dW"), (db, b.grad, "db")):
+            err = float((got.double().cpu() - ref).abs().max())
+            assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, (labels[-1], what, err, float(ref.abs().max()))
+    assert labels[0].startswith("wgrad_first") and labels[1].startswith("wgrad_mfma"), labels
