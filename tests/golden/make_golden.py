@@ -416,11 +416,43 @@ def labelprop(ref):
     print("labelprop logits sum %.6f" % float(y.double().sum()))
 
 
+def surface(ref):
+    """Host-side module surface: get_computations (model.py:513-536), pruneModelNew (model.py:45-57) and
+    count_zero_weights (model.py:59-66) of seeded reference models; numbers only."""
+    import contextlib, io
+    cfgs = {
+        "robo_s": dict(noScale=False, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128),
+        "robo_l": dict(noScale=True, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128),
+        "unet_s": dict(noScale=False, planes=8, depth=4, levels=3, bellySize=0, bellyPlanes=128, pool=True),
+        "unet_l": dict(noScale=True, planes=8, depth=4, levels=3, bellySize=0, bellyPlanes=128, pool=True),
+        "v2_s": dict(noScale=False, planes=8, depth=4, levels=1, bellySize=9, bellyPlanes=128, v2=True, classSize=3),
+    }
+    meta = {}
+    for tag, ctor in cfgs.items():
+        torch.manual_seed(12345678)
+        m = ref.ROBO_UNet(**ctor)
+        e = {"ctor": ctor, "sd_hash_init": sd_hash(m.state_dict()), "computations": [float(c) for c in m.get_computations()],
+             "zero_fraction_init": ref.count_zero_weights(m)}
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            masks = ref.pruneModelNew(m.parameters(), 0.1)
+        e["prune_ratio"] = 0.1
+        e["mask_counts"] = [int(k.sum()) for k in masks]
+        e["mask_shapes"] = [list(k.shape) for k in masks]
+        e["zero_fraction_pruned"] = ref.count_zero_weights(m)
+        e["computations_pruned"] = [float(c) for c in m.get_computations(True)]
+        e["sd_hash_pruned"] = sd_hash(m.state_dict())
+        meta[tag] = e
+        print("surface %-7s %d layers, %d masks, total %.4g -> pruned %.4g ops" %
+              (tag, len(e["computations"]), len(masks), sum(e["computations"]), sum(e["computations_pruned"])))
+    with open(os.path.join(HERE, "surface.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(THREADS)
     sys.path.insert(0, REF)
     import model as ref          # the reference, imported (never copied)
-    which = sys.argv[1:] or ["layers", "net", "lp", "dice_v2", "pbfcn"]
+    which = sys.argv[1:] or ["layers", "net", "lp", "dice_v2", "pbfcn", "surface"]
     if "layers" in which:
         layer_kats(ref)
     if "net" in which:
@@ -431,3 +463,5 @@ if __name__ == "__main__":
         dice_v2(ref)
     if "pbfcn" in which:
         pbfcn(ref)
+    if "surface" in which:
+        surface(ref)
