@@ -6,8 +6,8 @@
 // and tile, 46 % LDS bank-conflict cycles), not arithmetic: the layer is 2.1 GFMA against 0.43 GB of HBM traffic.  On gfx950 the fp32
 // vector rate equals the fp32 MFMA rate, so the layer runs as plain FMAs:
 //   * a workgroup owns a 16 x 64 output tile; a thread computes 4 consecutive pixels x 8 channels (32 accumulators);
-//   * the image tile (with halo) is staged plane by plane into LDS with coalesced row reads; the 27 x 8 filter sits in LDS as
-//     [tap][ci][8] and is read as wave-wide broadcasts (2 x 16 B per tap and input channel);
+//   * the image tile (with halo, widened to whole 16-byte quads of the image rows) is staged into LDS with ONE batch of 16-byte
+//     loads per thread; the 27 x 8 filter sits in LDS as [tap][ci][8] and is read as wave-wide broadcasts;
 //   * per input channel and filter row a thread reads its 4 + 2*dil input values once (16-byte aligned) and reuses them for the
 //     three taps of the row: 72 LDS reads for 864 FMAs;
 //   * bias / ReLU / BatchNorm sums are fused as in the MFMA kernels; workgroups are persistent and write ONE partial row.
@@ -22,14 +22,20 @@ __device__ __forceinline__ float cf_wave_sum(float v) {
 template <int DIL>
 __global__ __launch_bounds__(256) void conv_first_kernel(const ConvArgs a, int tiles_x, int tiles_y, int total_tiles) {
   constexpr int TY = 16, TX = 64, NT = 256;
-  constexpr int IH = TY + 2 * DIL, IWV = TX + 2 * DIL, IWP = (IWV + 3) / 4 * 4;      // staged rows / valid columns / row pitch
-  constexpr int SEG = 4 + 2 * DIL;                                                  // input values a thread needs per row
+  constexpr int IH = TY + 2 * DIL, IWV = TX + 2 * DIL;       // staged rows / valid columns
+  constexpr int IWP = TX + 8, NQ = IWP / 4;                  // LDS row: columns x0-4 .. x0+TX+3 (16-byte aligned quads of the image row)
+  constexpr int UV = 4;                                      // 16-byte loads in flight per thread (3 planes, dilation 1: one batch)
+  constexpr int SEG = 4 + 2 * DIL;                           // input values a thread needs per row
   __shared__ __attribute__((aligned(16))) float xs[4 * IH * IWP];
   __shared__ __attribute__((aligned(16))) float ws[9 * 4 * 8];
   __shared__ float red[4][16];
+  __shared__ float4 stg[4 * 256];                            // per wave: 2 output rows x 64 pixels x 8 channels (store transpose)
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = (tid & 15) * 4;
   const int Cin = a.Cin;
+  // whole image rows are 16-byte aligned quads: the tile is staged with ONE batch of 16-byte loads per thread (a quad lies entirely
+  // inside or outside the plane); otherwise (ragged widths, offset views) with scalar loads
+  const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
 
   // filter: packed [tap][CinP = 4][CoutP = 16] -> LDS [tap][ci][8]
   for (int e = tid; e < 9 * 4 * 8; e += NT) {
@@ -50,27 +56,53 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvArgs a, int t
     const int ty_i = t % tiles_y;
     const int n = t / tiles_y;
     const int y0 = ty_i * TY, x0 = tx_i * TX;
-    __syncthreads();                       // previous tile fully consumed (and the filter is in place)
-    // ---- stage Cin planes of (IH x IWV) with zero padding; 4 independent loads per thread in flight.  (Holding the whole next tile
-    // in registers across the arithmetic -- 19 slots -- was tried: 256 registers, one wave per SIMD, no faster.)
-    const int per_plane = IH * IWV, total = Cin * per_plane;
-    for (int e0 = tid; e0 < total; e0 += 4 * NT) {
-      float v[4];
-      int dst[4];
+    // previous tile fully consumed (and the filter is in place).  A bare barrier: __syncthreads() would also drain vmcnt, i.e. make
+    // every wave wait for the HBM round trip of the previous tile's output stores before it may request the next tile.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- stage Cin planes of IH rows with zero padding.  (Holding the whole next tile in registers across the arithmetic was
+    // tried: 256 registers, one wave per SIMD, no faster.)
+    if (vec) {
+      const int total = Cin * IH * NQ;
+      for (int e0 = tid; e0 < total; e0 += UV * NT) {
+        float4 v[UV];
+        int dst[UV];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int e = e0 + u * NT;
-        v[u] = 0.f; dst[u] = -1;
-        if (e < total) {
-          const int c = e / per_plane, r = e - c * per_plane;
-          const int iy = r / IWV, ix = r - iy * IWV;
-          const int gy = y0 - DIL + iy, gx = x0 - DIL + ix;
-          dst[u] = (c * IH + iy) * IWP + ix;
-          if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) v[u] = a.in[((size_t)n * Cin + c) * plane + (size_t)gy * a.W + gx];
+        for (int u = 0; u < UV; ++u) {       // branch-free: clamped address, zero selected afterwards (a branch around a load makes the
+          const int e = e0 + u * NT;         // compiler wait for it on the spot, one HBM round trip per load instead of one per batch)
+          const int ec = e < total ? e : total - 1;
+          const int c = ec / (IH * NQ), r = ec - c * (IH * NQ);
+          const int iy = r / NQ, j4 = r - iy * NQ;
+          const int gy = y0 - DIL + iy, gx = x0 - 4 + 4 * j4;
+          const int gyc = gy < 0 ? 0 : (gy < a.H ? gy : a.H - 1), gxc = gx < 0 ? 0 : (gx < a.W ? gx : a.W - 4);
+          dst[u] = e < total ? (c * IH + iy) * IWP + 4 * j4 : -1;
+          const float4 q = ld4(a.in + ((size_t)n * Cin + c) * plane + (size_t)gyc * a.W + gxc);
+          const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+          v[u] = make_float4(ok ? q.x : 0.f, ok ? q.y : 0.f, ok ? q.z : 0.f, ok ? q.w : 0.f);
         }
-      }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) if (dst[u] >= 0) xs[dst[u]] = v[u];
+        for (int u = 0; u < UV; ++u) if (dst[u] >= 0) *reinterpret_cast<float4*>(xs + dst[u]) = v[u];
+      }
+    } else {
+      const int per_plane = IH * IWV, total = Cin * per_plane;
+      for (int e0 = tid; e0 < total; e0 += 4 * NT) {
+        float v[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u * NT;
+          v[u] = 0.f; dst[u] = -1;
+          if (e < total) {
+            const int c = e / per_plane, r = e - c * per_plane;
+            const int iy = r / IWV, ix = r - iy * IWV;
+            const int gy = y0 - DIL + iy, gx = x0 - DIL + ix;
+            dst[u] = (c * IH + iy) * IWP + ix + 4 - DIL;
+            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) v[u] = a.in[((size_t)n * Cin + c) * plane + (size_t)gy * a.W + gx];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (dst[u] >= 0) xs[dst[u]] = v[u];
+      }
     }
     __syncthreads();
 
@@ -83,16 +115,19 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvArgs a, int t
     for (int c = 0; c < Cin; ++c) {
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky) {
+        // image columns x0+tx-DIL .. x0+tx+3+DIL = LDS columns tx+4-DIL .. tx+7+DIL of the row
         const float* row = xs + (c * IH + ty + ky * DIL) * IWP + tx;
         float seg[SEG];
-        const float4 q0 = *reinterpret_cast<const float4*>(row);
-        seg[0] = q0.x; seg[1] = q0.y; seg[2] = q0.z; seg[3] = q0.w;
+        const float4 q1 = *reinterpret_cast<const float4*>(row + 4);
         if (DIL == 1) {
-          const float2 q1 = *reinterpret_cast<const float2*>(row + 4);
-          seg[4] = q1.x; seg[5] = q1.y;
+          seg[0] = row[3];
+          seg[1] = q1.x; seg[2] = q1.y; seg[3] = q1.z; seg[4] = q1.w;
+          seg[5] = row[8];
         } else {
-          const float4 q1 = *reinterpret_cast<const float4*>(row + 4);
-          seg[4] = q1.x; seg[5] = q1.y; seg[SEG - 2] = q1.z; seg[SEG - 1] = q1.w;
+          const float2 q0 = *reinterpret_cast<const float2*>(row + 2), q2 = *reinterpret_cast<const float2*>(row + 8);
+          seg[0] = q0.x; seg[1] = q0.y;
+          seg[2] = q1.x; seg[3] = q1.y; seg[4] = q1.z; seg[5] = q1.w;
+          seg[SEG - 2] = q2.x; seg[SEG - 1] = q2.y;
         }
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
@@ -109,24 +144,44 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvArgs a, int t
       }
     }
 
-    // ---- bias, ReLU, store (128 contiguous bytes per thread), statistics
+    // ---- bias, ReLU, statistics; then the stores.  A thread holds 4 pixels x 8 channels = 128 contiguous bytes, so a direct store
+    // instruction would touch 64 different 128-byte lines with 16 bytes each (measured: the kernel ran at 2.2 TB/s with the vector
+    // ALU 44 % busy).  The wave transposes through a private 4 KB LDS window instead (two passes of two rows; quads rotated within
+    // each 128-byte block against bank conflicts) and every store instruction writes 1 KB of consecutive memory.
     const int gy = y0 + ty;
-    if (gy < a.H) {
-      float* orow = a.out + ((size_t)(n * a.H + gy) * a.W + x0 + tx) * 8;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        if (x0 + tx + p < a.W) {
-          float v[8];
+    for (int p = 0; p < 4; ++p) {
+      const bool okp = gy < a.H && x0 + tx + p < a.W;
 #pragma unroll
-          for (int co = 0; co < 8; ++co) {
-            v[co] = acc[p][co] + bias[co];
-            if (a.flags & RCV_F_RELU) v[co] = fmaxf(v[co], 0.f);
-            s1[co] += v[co];
-            s2[co] = fmaf(v[co], v[co], s2[co]);
-          }
-          *reinterpret_cast<float4*>(orow + p * 8) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(orow + p * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      for (int co = 0; co < 8; ++co) {
+        float v = acc[p][co] + bias[co];
+        if (a.flags & RCV_F_RELU) v = fmaxf(v, 0.f);
+        acc[p][co] = v;
+        if (okp) { s1[co] += v; s2[co] = fmaf(v, v, s2[co]); }
+      }
+    }
+    {
+      const int lane = tid & 63, wv = tid >> 6;
+      float4* st = stg + wv * 256;                              // [2 rows][128 quads]
+      const int lrow = lane >> 4, t4 = lane & 15;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        if ((lrow >> 1) == pass) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)                           // quad j = 2 p + h of this thread's 8; block = t4
+            st[(lrow & 1) * 128 + 8 * t4 + ((j + t4) & 7)] = make_float4(acc[j >> 1][4 * (j & 1)], acc[j >> 1][4 * (j & 1) + 1],
+                                                                         acc[j >> 1][4 * (j & 1) + 2], acc[j >> 1][4 * (j & 1) + 3]);
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave: LDS executes its instructions in order
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int f = lane + 64 * k;                          // quad index in the 2 x 128 window
+          const int r = f >> 7, fq = f & 127, blk = fq >> 3;
+          const float4 v = st[r * 128 + 8 * blk + (((fq & 7) + blk) & 7)];
+          const int oy = y0 + wv * 4 + pass * 2 + r, ox = x0 + (fq >> 1);
+          if (oy < a.H && ox < a.W) *reinterpret_cast<float4*>(a.out + ((size_t)(n * a.H + oy) * a.W + x0) * 8 + fq * 4) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // reads done before the window is rewritten
       }
     }
   }
