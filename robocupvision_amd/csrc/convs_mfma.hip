@@ -100,22 +100,21 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
         }
       }
     } else {
+      // Branch-free: clamped addresses, validity kept in okmask (write_x zeroes what lies outside).  With the loads inside divergent
+      // branches the compiler waits for each of them on the spot, and nothing stays in flight across the contraction.
       const int q = tid % Q;
 #pragma unroll
       for (int u = 0; u < XMAX; ++u) {
         const int pix = tid / Q + u * STEP;
-        px[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (TWO) pa[TWO ? u : 0] = px[u];
-        if (pix < npix) {
-          const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
-          const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
-          if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
-            okmask |= 1u << u;
-            const size_t off = ((size_t)(ti.n * a.H + gy) * a.W + gx) * a.Cin + 4 * q;
-            px[u] = ld4(a.in + off);
-            if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
-          }
-        }
+        const int pixc = pix < npix ? pix : npix - 1;
+        const int iy = fd_div(pixc, a.fdIW), ix = pixc - iy * a.IW;
+        const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
+        const bool inside = pix < npix && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        const int gyc = gy < 0 ? 0 : (gy < a.H ? gy : a.H - 1), gxc = gx < 0 ? 0 : (gx < a.W ? gx : a.W - 1);
+        okmask |= (inside ? 1u : 0u) << u;
+        const size_t off = ((size_t)(ti.n * a.H + gyc) * a.W + gxc) * a.Cin + 4 * q;
+        px[u] = ld4(a.in + off);
+        if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
       }
     }
   };
@@ -135,7 +134,10 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
 
   while (tile < a.total_tiles) {
     const TileInfo ti = decode_tile<KIND>(a, tile, COT);
-    __syncthreads();                 // every wave is done reading the previous tile (and the filter is in place)
+    // every wave is done reading the previous tile (and the filter is in place).  Bare barriers in this loop: the fence of
+    // __syncthreads() would drain vmcnt, i.e. wait for the prefetch (and for the previous tile's output stores).
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (a.flags & RCV_F_DBG_NOSTAGE) {
       // profiling ablation: no LDS writes, no global loads
     } else if (TWO) {
@@ -150,8 +152,11 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
       }
     }
     const int ntile = tile + gridDim.x;
-    if (ntile < a.total_tiles && !(a.flags & RCV_F_DBG_NOSTAGE)) prefetch(ntile);      // in flight during the contraction and the stores below
-    __syncthreads();
+    // next tile's loads: in flight during the contraction and the stores below.  Unconditional (the last iteration re-requests its
+    // own tile, L2 hits): behind a branch the compiler parks a vmcnt(0) in front of the contraction where the two paths meet.
+    prefetch(ntile < a.total_tiles ? ntile : tile);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
     // ---- contraction
     if (a.flags & RCV_F_DBG_NOMFMA) { tile = ntile; continue; }      // profiling ablation
