@@ -105,7 +105,7 @@ __device__ __forceinline__ void stage_input(const ConvArgs& a, float* xl, const 
 
 // Epilogue shared by the conv kernels: bias / ReLU / skip-gradient add, 16-byte NHWC stores, and the per-tile
 // BatchNorm partial sums (forward or backward), reduced in a fixed order through `red` ([WAVES_N][2][COT]).
-template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND, int EB = (WM == 1 ? WN : 0)>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const TileInfo& ti, f32x4 (&acc)[WM][WN], float* red, int tid) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int COT = WM * WAVES_M * 16;
@@ -130,42 +130,115 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const TileInfo&
         if (a.stats == RCV_STATS_BWD_DEC) { e0 = ld4(a.epi_c + co); e1 = ld4(a.epi_c + a.Cout + co); }
         if (a.stats == RCV_STATS_BWD_DEC || a.stats == RCV_STATS_BWD_ENC) mu = ld4(a.epi_c + 2 * a.Cout + co);
       }
+      // The residual / BN-backward operands of all WN pixel blocks are requested in one batch, branch-free (a lane without an output
+      // element reads element 0 and discards it): with each load inside its own `if (ok)` the compiler waits for it on the spot,
+      // 2 * WN serialized HBM round trips per channel block in the data-gradient kernels.
+      if constexpr (EB == 0) {
+        // 32-channel-per-wave tiles (WM = 2): the batch below costs 12 registers and with them the fourth wave per SIMD, which the
+        // forward launches of the same kernel (no epilogue operands) pay for: measured +2..7 % there against -1 % in the backward
+        // launches.  These tiles load their epilogue operands where they are used.
 #pragma unroll
-      for (int b = 0; b < WN; ++b) {
-        const int p = (wave_n * WN + b) * 16 + l15;
-        const int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
-        int oy = ti.y0 + ty, ox = ti.x0 + tx;
-        bool ok = ty < a.R && co_ok;
-        if (KIND != KIND_GATHER) {
-          ok = ok && oy < a.H && ox < a.W;
-          oy = 2 * oy + py; ox = 2 * ox + pxx;
-        } else {
-          ok = ok && oy < a.Ho && ox < a.Wo;
+        for (int b = 0; b < WN; ++b) {
+          const int p = (wave_n * WN + b) * 16 + l15;
+          const int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
+          int oy = ti.y0 + ty, ox = ti.x0 + tx;
+          bool ok = ty < a.R && co_ok;
+          if (KIND != KIND_GATHER) {
+            ok = ok && oy < a.H && ox < a.W;
+            oy = 2 * oy + py; ox = 2 * ox + pxx;
+          } else {
+            ok = ok && oy < a.Ho && ox < a.Wo;
+          }
+          if (!ok) continue;
+          const size_t off = ((size_t)(ti.n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+          float4 v = make_float4(acc[m][b][0] + bias.x, acc[m][b][1] + bias.y, acc[m][b][2] + bias.z, acc[m][b][3] + bias.w);
+          if (a.flags & RCV_F_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (a.flags & RCV_F_RESID) { const float4 rr = ld4(a.resid + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+          *reinterpret_cast<float4*>(a.out + off) = v;
+          if (a.stats == RCV_STATS_FWD) {
+            s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+            s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
+            s2[m][2] = fmaf(v.z, v.z, s2[m][2]); s2[m][3] = fmaf(v.w, v.w, s2[m][3]);
+          } else if (a.stats == RCV_STATS_BWD_ENC) {
+            const float4 e = ld4(a.epi_aux + off);
+            s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+            s2[m][0] = fmaf(v.x, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(v.y, e.y - mu.y, s2[m][1]);
+            s2[m][2] = fmaf(v.z, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(v.w, e.w - mu.w, s2[m][3]);
+          } else if (a.stats == RCV_STATS_BWD_DEC) {
+            const float4 e = ld4(a.epi_aux + off);
+            const float gx = fmaf(e.x, e0.x, e1.x) > 0.f ? v.x : 0.f;
+            const float gy = fmaf(e.y, e0.y, e1.y) > 0.f ? v.y : 0.f;
+            const float gz = fmaf(e.z, e0.z, e1.z) > 0.f ? v.z : 0.f;
+            const float gw = fmaf(e.w, e0.w, e1.w) > 0.f ? v.w : 0.f;
+            s1[m][0] += gx; s1[m][1] += gy; s1[m][2] += gz; s1[m][3] += gw;
+            s2[m][0] = fmaf(gx, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(gy, e.y - mu.y, s2[m][1]);
+            s2[m][2] = fmaf(gz, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(gw, e.w - mu.w, s2[m][3]);
+          }
         }
-        if (!ok) continue;
-        const size_t off = ((size_t)(ti.n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
-        float4 v = make_float4(acc[m][b][0] + bias.x, acc[m][b][1] + bias.y, acc[m][b][2] + bias.z, acc[m][b][3] + bias.w);
-        if (a.flags & RCV_F_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (a.flags & RCV_F_RESID) { const float4 rr = ld4(a.resid + off); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-        *reinterpret_cast<float4*>(a.out + off) = v;
-        if (a.stats == RCV_STATS_FWD) {
-          s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
-          s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
-          s2[m][2] = fmaf(v.z, v.z, s2[m][2]); s2[m][3] = fmaf(v.w, v.w, s2[m][3]);
-        } else if (a.stats == RCV_STATS_BWD_ENC) {
-          const float4 e = ld4(a.epi_aux + off);
-          s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
-          s2[m][0] = fmaf(v.x, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(v.y, e.y - mu.y, s2[m][1]);
-          s2[m][2] = fmaf(v.z, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(v.w, e.w - mu.w, s2[m][3]);
-        } else if (a.stats == RCV_STATS_BWD_DEC) {
-          const float4 e = ld4(a.epi_aux + off);
-          const float gx = fmaf(e.x, e0.x, e1.x) > 0.f ? v.x : 0.f;
-          const float gy = fmaf(e.y, e0.y, e1.y) > 0.f ? v.y : 0.f;
-          const float gz = fmaf(e.z, e0.z, e1.z) > 0.f ? v.z : 0.f;
-          const float gw = fmaf(e.w, e0.w, e1.w) > 0.f ? v.w : 0.f;
-          s1[m][0] += gx; s1[m][1] += gy; s1[m][2] += gz; s1[m][3] += gw;
-          s2[m][0] = fmaf(gx, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(gy, e.y - mu.y, s2[m][1]);
-          s2[m][2] = fmaf(gz, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(gw, e.w - mu.w, s2[m][3]);
+      } else {
+        const bool bwd_stats = a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC;
+  #pragma unroll
+        for (int b0 = 0; b0 < WN; b0 += (EB > 0 ? EB : 1)) {       // EB blocks per batch (register budget of the caller)
+          bool okb[EB > 0 ? EB : 1];
+          size_t offb[EB > 0 ? EB : 1];
+  #pragma unroll
+          for (int i = 0; i < EB; ++i) {
+            const int b = b0 + i;
+            okb[i] = false; offb[i] = 0;
+            if (b < WN) {
+              const int p = (wave_n * WN + b) * 16 + l15;
+              const int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
+              int oy = ti.y0 + ty, ox = ti.x0 + tx;
+              bool ok = ty < a.R && co_ok;
+              if (KIND != KIND_GATHER) {
+                ok = ok && oy < a.H && ox < a.W;
+                oy = 2 * oy + py; ox = 2 * ox + pxx;
+              } else {
+                ok = ok && oy < a.Ho && ox < a.Wo;
+              }
+              okb[i] = ok;
+              offb[i] = ok ? ((size_t)(ti.n * a.Ho + oy) * a.Wo + ox) * a.Cout + co : 0;
+            }
+          }
+          float4 rrb[EB > 0 ? EB : 1], eb[EB > 0 ? EB : 1];
+          if (a.flags & RCV_F_RESID) {
+  #pragma unroll
+            for (int i = 0; i < EB; ++i) if (b0 + i < WN) rrb[i] = ld4(a.resid + offb[i]);
+          }
+          if (bwd_stats) {
+  #pragma unroll
+            for (int i = 0; i < EB; ++i) if (b0 + i < WN) eb[i] = ld4(a.epi_aux + offb[i]);
+          }
+  #pragma unroll
+          for (int i = 0; i < EB; ++i) {
+            const int b = b0 + i;
+            if (b >= WN) continue;
+            if (!okb[i]) continue;
+            const size_t off = offb[i];
+            float4 v = make_float4(acc[m][b][0] + bias.x, acc[m][b][1] + bias.y, acc[m][b][2] + bias.z, acc[m][b][3] + bias.w);
+            if (a.flags & RCV_F_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (a.flags & RCV_F_RESID) { const float4 rr = rrb[i]; v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+            *reinterpret_cast<float4*>(a.out + off) = v;
+            if (a.stats == RCV_STATS_FWD) {
+              s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+              s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
+              s2[m][2] = fmaf(v.z, v.z, s2[m][2]); s2[m][3] = fmaf(v.w, v.w, s2[m][3]);
+            } else if (a.stats == RCV_STATS_BWD_ENC) {
+              const float4 e = eb[i];
+              s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+              s2[m][0] = fmaf(v.x, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(v.y, e.y - mu.y, s2[m][1]);
+              s2[m][2] = fmaf(v.z, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(v.w, e.w - mu.w, s2[m][3]);
+            } else if (a.stats == RCV_STATS_BWD_DEC) {
+              const float4 e = eb[i];
+              const float gx = fmaf(e.x, e0.x, e1.x) > 0.f ? v.x : 0.f;
+              const float gy = fmaf(e.y, e0.y, e1.y) > 0.f ? v.y : 0.f;
+              const float gz = fmaf(e.z, e0.z, e1.z) > 0.f ? v.z : 0.f;
+              const float gw = fmaf(e.w, e0.w, e1.w) > 0.f ? v.w : 0.f;
+              s1[m][0] += gx; s1[m][1] += gy; s1[m][2] += gz; s1[m][3] += gw;
+              s2[m][0] = fmaf(gx, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(gy, e.y - mu.y, s2[m][1]);
+              s2[m][2] = fmaf(gz, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(gw, e.w - mu.w, s2[m][3]);
+            }
+          }
         }
       }
     }
@@ -551,7 +624,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
       TileInfo tp = ti;
       tp.py = ph >> 1; tp.px = ph & 1;
       if (ph) __syncthreads();                      // `red` of the previous parity has been consumed
-      conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND_TPHASE>(a, tp, acc[ph], red, tid);
+      conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND_TPHASE, 2>(a, tp, acc[ph], red, tid);   // 160 accumulator registers are live: small batches
     }
   } else {
     conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND>(a, ti, acc[0], red, tid);
