@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (a.flags & RCV_F_DBG_NOSTAGE) {
-      // profiling ablation: no LDS writes, no global loads
+      // profiling ablation: no LDS writes (the prefetch loads below are still issued: they are unconditional)
     } else if (TWO) {
       if (a.in_mode == RCV_LOAD_GRAD_ENC) narrow_write_x<RCV_LOAD_GRAD_ENC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid);
       else narrow_write_x<RCV_LOAD_GRAD_DEC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid);
