@@ -472,16 +472,36 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   int per_cu = wt.SPEC ? 1 : 2;                     // SPEC: 512 threads, two LDS buffers => one workgroup per CU
   if (const char* ev = getenv("RCV_WGRAD_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4 && !wt.SPEC) per_cu = o; }
   const size_t budget = (wt.SPEC ? 78 : 160 / per_cu) * 1024 / sizeof(float);   // SPEC: per buffer
+  // Pixel tile: among the (row segment, rows) shapes that fit the LDS budget, the one that stages the fewest global bytes per
+  // pointwise pixel (the gathered tile carries a halo of 2*dil rows and columns: a 1 x 80 tile of a stride-1 layer reads its gathered
+  // operand 3.1 times, a 4 x 40 tile 1.6 times); ties go to the larger tile.  RCV_WGRAD_WIDE=1 restores "widest row segment first".
   int bestR = 0, bestWt = 0;
-  for (int nx = 1; nx <= Wp && bestR == 0; ++nx) {
-    const int Wt = ceil_div(Wp, nx), Wt4 = round_up(Wt, 4);
-    const int IW = (Wt4 - 1) * s + 2 * d + 1;
-    for (int R = Hp; R >= 1; --R) {
-      const int IH = (R - 1) * s + 2 * d + 1;
-      if (R * Wt4 > (wt.SPEC ? 1024 : 640) || IH * IW >= 65536) continue;
-      if ((size_t)R * Wt4 * pl->SP + (size_t)IH * IW * pl->SG > budget) continue;
-      bestR = R; bestWt = Wt;
-      break;
+  {
+    const int m1 = op->i[RCV_I_INMODE], m2 = op->i[RCV_I_INMODE2];
+    const double cG = (double)CA * ((m1 == RCV_LOAD_GRAD_ENC || m1 == RCV_LOAD_GRAD_DEC) ? 2 : 1);
+    const double cP = (double)CB * ((m2 == RCV_LOAD_GRAD_ENC || m2 == RCV_LOAD_GRAD_DEC) ? 2 : 1);
+    const bool wide_first = getenv("RCV_WGRAD_WIDE") != nullptr;
+    const int max_px = wt.SPEC ? 1024 : 640;
+    double best_cost = 1e30;
+    for (int nx = 1; nx <= Wp && nx <= 32; ++nx) {
+      const int Wt = ceil_div(Wp, nx), Wt4 = round_up(Wt, 4);
+      if (nx > 1 && Wt == ceil_div(Wp, nx - 1)) continue;
+      const int IW = (Wt4 - 1) * s + 2 * d + 1;
+      for (int R = Hp; R >= 1; --R) {
+        const int IH = (R - 1) * s + 2 * d + 1;
+        if (R * Wt4 > max_px || IH * IW >= 65536) continue;
+        if ((size_t)R * Wt4 * pl->SP + (size_t)IH * IW * pl->SG > budget) continue;
+        const int Re = ceil_div(Hp, ceil_div(Hp, R));            // rows actually used (equal row groups)
+        const int IHe = (Re - 1) * s + 2 * d + 1;
+        const double ntile = (double)ceil_div(Wp, Wt) * ceil_div(Hp, Re);   // ragged last tiles cost as much as full ones
+        const double cost = ntile * ((double)Re * Wt4 * cP + (double)IHe * IW * cG) / ((double)Hp * Wp);
+        if (wide_first) { if (bestR == 0) { bestR = R; bestWt = Wt; } break; }
+        if (cost < best_cost * 0.995 || (cost < best_cost * 1.005 && R * Wt > bestR * bestWt)) {
+          best_cost = cost < best_cost ? cost : best_cost; bestR = R; bestWt = Wt;
+        }
+        break;                                                   // fewer rows of the same segment only add halo
+      }
+      if (wide_first && bestR) break;
     }
   }
   RCV_CHECK_ARG(bestR > 0, "wgrad: no pixel tile fits (plane %dx%d)", Hp, Wp);
