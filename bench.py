@@ -192,6 +192,12 @@ def main():
                    "loss_after": round(metrics["loss"], 6)},
     }
 
+    eng = model._get_engine()
+    plans = [pl for (shape, training), pl in eng.plans.items() if training and pl.side_decided]
+    if plans:      # schedule of the backward list the engine measured and kept on its first pass (engine.SIDE_STREAM_MODE)
+        out["config"]["filter_gradients_on_second_stream"] = bool(plans[0].side_on)
+        if plans[0].side_ms:
+            out["config"]["backward_ms_two_streams_vs_one"] = [round(v, 3) for v in plans[0].side_ms]
     if rank == 0 and not args.no_roofline:
         rows = model._get_engine().profile_last(reps=3)
         by = {}
