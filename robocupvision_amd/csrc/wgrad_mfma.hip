@@ -70,7 +70,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
   const bool p_two = a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC;
   const bool g_two = a.g_mode == RCV_LOAD_GRAD_ENC || a.g_mode == RCV_LOAD_GRAD_DEC;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int UNR = (FOLD || (SPEC && WAVES_K != 2)) ? 8 : 4;     // folded (<= 8 channel) tiles are HBM bound: more loads in flight
+  constexpr int UNR = (FOLD || (!SPEC && WM * WN == 1) || (SPEC && WAVES_K != 2)) ? 8 : 4;     // loads in flight per staging thread, as the register budget of the tile allows (<= 256 with two waves per SIMD)
   auto stage = [&](int tile, float* pl, float* gl) {
     int t = tile;
     const int tx_i = t % a.tiles_x;
@@ -256,19 +256,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
   const int ksteps = np_pix / 4;
   const int a_lane = l4 * a.SP + (wave_m * WM) * 16 + l15;
 
+  // The k-step slice of this wave (wave_k is the same for all its lanes: made a scalar so that the loop and its pixel arithmetic run
+  // on the scalar unit).
+  const int wave_k_s = __builtin_amdgcn_readfirstlane(wave_k);
+  auto load_ops = [&](const float* pl, const float* gl, int j, float (&av)[WM], float (&bv)[NACC]) {
+    const int p0 = 4 * j;
+    const int ty = fd_div(p0, a.fdWt4), tx = p0 - ty * a.Wt4;
+#pragma unroll
+    for (int m = 0; m < WM; ++m) av[m] = pl[p0 * a.SP + a_lane + m * 16];
+    const float* gj = gl + ((ty * s) * a.IW + tx * s) * a.SG;
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) bv[t] = gj[loff[t]];
+  };
+  auto mfma_ops = [&](const float (&av)[WM], const float (&bv)[NACC]) {
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+      for (int m = 0; m < WM; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[t], acc[t][m], 0, 0, 0);
+  };
+  // Tiles with few MFMAs per k-step (2..18: the <= 32-channel tiles, 64..576 cycles of matrix work) read the operands of k-step j+1
+  // while the MFMAs of k-step j run: with the reads issued right in front of their MFMAs every k-step began with an exposed LDS
+  // round trip and the matrix pipe of the 16 x 16 tile was 36 % busy.  (The 36-MFMA k-steps of the wave-specialised tiles hide it
+  // by themselves: measured, no difference there.)
+  constexpr bool PIPE = !SPEC;
   auto contract = [&](const float* pl, const float* gl) {
-    for (int j = wave_k; j < ksteps; j += WAVES_K) {
-      const int p0 = 4 * j;
-      const int ty = fd_div(p0, a.fdWt4), tx = p0 - ty * a.Wt4;
-      float av[WM];
-#pragma unroll
-      for (int m = 0; m < WM; ++m) av[m] = pl[p0 * a.SP + a_lane + m * 16];
-      const float* gj = gl + ((ty * s) * a.IW + tx * s) * a.SG;
-#pragma unroll
-      for (int t = 0; t < NACC; ++t) {
-        const float bv = gj[loff[t]];
-#pragma unroll
-        for (int m = 0; m < WM; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv, acc[t][m], 0, 0, 0);
+    if (PIPE) {
+      // (reads are unconditional -- past the end they repeat the last k-step and are discarded: behind a branch the compiler
+      // waits for ALL outstanding LDS reads where the paths meet, the prefetched set included)
+      float av0[WM], bv0[NACC], av1[WM], bv1[NACC];
+      const int jlast = ksteps - 1;
+      int j = wave_k_s;
+      load_ops(pl, gl, j < jlast ? j : jlast, av0, bv0);
+      for (; j < ksteps; j += 2 * WAVES_K) {
+        const int j1 = j + WAVES_K, j2 = j + 2 * WAVES_K;
+        load_ops(pl, gl, j1 < jlast ? j1 : jlast, av1, bv1);
+        mfma_ops(av0, bv0);
+        load_ops(pl, gl, j2 < jlast ? j2 : jlast, av0, bv0);
+        if (j1 < ksteps) mfma_ops(av1, bv1);
+      }
+    } else {
+      for (int j = wave_k_s; j < ksteps; j += WAVES_K) {
+        float av[WM], bv[NACC];
+        load_ops(pl, gl, j, av, bv);
+        mfma_ops(av, bv);
       }
     }
   };
