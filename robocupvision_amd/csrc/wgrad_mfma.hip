@@ -70,7 +70,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
   const bool p_two = a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC;
   const bool g_two = a.g_mode == RCV_LOAD_GRAD_ENC || a.g_mode == RCV_LOAD_GRAD_DEC;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  constexpr int UNR = (FOLD || (!SPEC && WM * WN == 1) || (SPEC && WAVES_K != 2)) ? 8 : 4;     // loads in flight per staging thread, as the register budget of the tile allows (<= 256 with two waves per SIMD)
+  constexpr int UNR = (FOLD || (SPEC && WAVES_K != 2)) ? 8 : 4;     // folded (<= 8 channel) tiles are HBM bound: more loads in flight (8 on the 16 x 16 tile: measured, no gain; on the 32 x 16 tiles > 256 registers)
   auto stage = [&](int tile, float* pl, float* gl) {
     int t = tile;
     const int tx_i = t % a.tiles_x;
