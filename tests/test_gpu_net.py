@@ -245,6 +245,23 @@ def test_scheduling_variants_are_bitwise_identical(monkeypatch):
             assert torch.equal(out["grads"][k], ref["grads"][k]), (name, k)
 
 
+def test_backward_schedule_is_measured_once_per_plan():
+    """engine.SIDE_STREAM_MODE == "auto": the first backward pass of a plan times the list with the filter gradients on the second
+    stream and on the caller's stream and keeps the faster; the measurement re-runs the list, which must not change any result."""
+    x, t = O.synthetic_batch(2, 48, 64)
+    model = build(dict(noScale=True)).to(DEV)
+    a = hip_step(model, x.to(DEV), t.to(DEV), do_step=False)
+    eng = model._get_engine()
+    plans = [pl for (shape, training), pl in eng.plans.items() if training]
+    assert len(plans) == 1 and plans[0].side_decided
+    if plans[0].side_ms is not None:                     # (None when the schedule is forced by the environment)
+        assert len(plans[0].side_ms) == 2 and min(plans[0].side_ms) > 0
+        assert plans[0].side_on == (plans[0].side_ms[0] <= plans[0].side_ms[1])
+    b = hip_step(model, x.to(DEV), t.to(DEV), do_step=False)      # second step: no measurement, same numbers
+    for k in a["grads"]:
+        assert torch.equal(a["grads"][k], b["grads"][k]), k
+
+
 def test_grad_accumulation_semantics():
     """Two backward passes without zero_grad accumulate (param.grad aliases the engine buffer otherwise)."""
     x, t = O.synthetic_batch(1, 16, 24)
