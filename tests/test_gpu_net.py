@@ -368,6 +368,9 @@ def test_labelprop_inference_vs_golden():
     (dict(noScale=True), 2, 80, 112),                      # tiles that do not divide the planes
     (dict(noScale=False), 5, 24, 200),                     # odd batch, very wide / short planes
     (dict(noScale=False, levels=3, bellySize=0, pool=True), 3, 56, 72),   # U-Net (max-pool) on ragged tiles
+    (dict(noScale=False), 3, 136, 104),                    # planes no filter-gradient tile shape divides (17x13 at the bottom)
+    (dict(noScale=True), 1, 208, 176),                     # batch 1, 13x11 bottom planes
+    (dict(noScale=False, v2=True, classSize=3, levels=1, bellySize=9), 2, 72, 88),   # v2 net (concat skips, 3x3 classifier)
 ])
 def test_ragged_shapes_vs_oracle(ctor, B, H, W):
     """Edge shapes (partial tiles, 1-pixel planes, odd batches) against the CPU oracle on the box."""
@@ -397,6 +400,8 @@ def test_ragged_shapes_vs_oracle(ctor, B, H, W):
         tiny_bottom = ctor.get("noScale") and B * (H // 16) * (W // 16) < 64
         upstream = n.startswith("downPart") or n.startswith("PB.PB_1")
         tol = 0.2 if (tiny_bottom and upstream) else 5e-3
+        if n.endswith("conv.bias") or n.endswith("bn.weight") or n.endswith("bn.bias"):
+            tol = max(tol, 2e-2)      # per-channel sums that cancel to ~1e-4 of their terms: the fp32 oracle itself moves by ~1e-3..1e-2 on them
         assert rel <= tol, "grad %s vs oracle: relative L2 error %.3e" % (n, rel)
 
 
