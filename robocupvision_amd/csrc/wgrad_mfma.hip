@@ -513,11 +513,19 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
     const bool wide_first = getenv("RCV_WGRAD_WIDE") != nullptr;
     const int max_px = wt.SPEC ? 1024 : 640;
     double best_cost = 1e30;
-    for (int nx = 1; nx <= Wp && nx <= 32; ++nx) {
+    int prevWt = 0;
+    for (int nx = 1; nx <= Wp; ++nx) {                 // every distinct segment width (~2 sqrt(Wp) of them)
       const int Wt = ceil_div(Wp, nx), Wt4 = round_up(Wt, 4);
-      if (nx > 1 && Wt == ceil_div(Wp, nx - 1)) continue;
+      if (Wt == prevWt) { if (Wt <= 4) break; continue; }
+      prevWt = Wt;
       const int IW = (Wt4 - 1) * s + 2 * d + 1;
-      for (int R = Hp; R >= 1; --R) {
+      // largest row count within the pixel cap and the LDS budget:  R Wt4 SP + ((R-1) s + 2d+1) IW SG <= budget
+      long rmax = max_px / Wt4;
+      const long fixed = (long)(2 * d + 1 - s) * IW * pl->SG, per_row = (long)Wt4 * pl->SP + (long)s * IW * pl->SG;
+      if ((long)budget - fixed < per_row) continue;
+      if (((long)budget - fixed) / per_row < rmax) rmax = ((long)budget - fixed) / per_row;
+      if (rmax > Hp) rmax = Hp;
+      for (int R = (int)rmax; R >= 1; --R) {
         const int IH = (R - 1) * s + 2 * d + 1;
         if (R * Wt4 > max_px || IH * IW >= 65536) continue;
         if ((size_t)R * Wt4 * pl->SP + (size_t)IH * IW * pl->SG > budget) continue;
