@@ -765,7 +765,8 @@ class Engine:
     def _decide_side_stream(self, plan: Plan, ops: L.OpList):
         """Times the backward list both ways (it only overwrites engine buffers: re-running it is harmless) and keeps the faster."""
         plan.side_decided = True
-        if not SIDE_STREAM_WGRAD or SIDE_STREAM_MODE != "auto" or self.grad_ready_cb is not None:
+        capturing = torch.cuda.is_current_stream_capturing()          # (no event synchronisation inside a graph capture)
+        if not SIDE_STREAM_WGRAD or SIDE_STREAM_MODE != "auto" or self.grad_ready_cb is not None or capturing:
             plan.side_on = SIDE_STREAM_WGRAD
         else:
             stream = torch.cuda.current_stream(self.device)
