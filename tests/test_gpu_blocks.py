@@ -202,3 +202,44 @@ def test_first_layer_filter_gradient_kernels(N, H, W, dil, mode2, monkeypatch):
             err = float((got.double().cpu() - ref).abs().max())
             assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, (labels[-1], what, err, float(ref.abs().max()))
     assert labels[0].startswith("wgrad_first") and labels[1].startswith("wgrad_mfma"), labels
+
+
+def test_adam_l1_named_entry_points_vs_torch():
+    """rcv_adam_l1_step / rcv_adam_l1_step_metrics called through ctypes as a reference-side binding would:
+    three steps against torch.optim.Adam on `grad + decay*sign(p)` (train.py:23-27,52-55,67), and the metrics row against the
+    sums train.py:52-53,69-73 keep (loss + decay*sum|p| with the PRE-update parameters, the L1 term, correct pixels, steps)."""
+    import ctypes as C
+    from robocupvision_amd import _lib as L
+    lib, h = L.load(), L.handle(0)
+    dev = torch.device("cuda:0")
+    n, decay, lr = 100003, 1e-3, 2e-3
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.Adam([ref], lr=lr)
+    p = p0.clone().to(dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    metrics = torch.zeros(4, dtype=torch.float64, device=dev)
+    op = L.make_op(L.OP_ADAM_L1, 0, count=n)
+    ws = torch.zeros((L.op_workspace(h, op) + 7) // 8, dtype=torch.float64, device=dev)
+    rows = op.i[L.RCV_I_NPART]
+    fn = lib.rcv_adam_l1_step_metrics
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p] * 6 + [C.c_int64] + [C.c_float] * 5 + [C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    exp = [0.0, 0.0, 0.0, 0.0]
+    st = torch.cuda.current_stream().cuda_stream
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g)
+        stats = torch.tensor([0.5 * step, 0.0, 7.0 * step, 0.0], dtype=torch.float32)
+        reg = decay * float(ref.detach().abs().sum())
+        exp = [exp[0] + 0.5 * step + reg, exp[1] + reg, exp[2] + 7.0 * step, exp[3] + 1]
+        ref.grad = grad.double() + decay * torch.sign(ref.detach())
+        opt.step()
+        gd, sd = grad.to(dev), stats.to(dev)
+        rc = fn(h, p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), None, n, lr, 0.9, 0.999, 1e-8, decay, step, 1.0,
+                metrics.data_ptr(), sd.data_ptr(), ws.data_ptr(), rows, st)
+        assert rc == 0, lib.rcv_last_error()
+        torch.cuda.synchronize()
+        assert float((p.double().cpu() - ref.detach()).abs().max()) <= 2e-6
+    got = metrics.cpu().tolist()
+    for a, b in zip(got, exp):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (got, exp)
