@@ -26,7 +26,11 @@ struct ConvArgs {
   uint32_t flags;
   int wl_floats, xl_floats;    // LDS carve: filter tile, input tile (then constants, then reduction scratch)
   int xpitch;                  // floats per staged input pixel (see conv_xpitch)
+  int xk;                      // conv_dma_kernel: channels per staged input chunk (8 or 16)
   FastDiv fdWt, fdIW;
+#ifdef RCV_STAMPS
+  unsigned long long* stamps;  // diagnostic build: per wave [12] cycle sums (conv_dma_kernel)
+#endif
 };
 
 struct TileInfo {
@@ -90,6 +94,7 @@ struct ConvPlan {
   int wl_floats, xl_floats;
   int narrow;            // 1: convs_mfma.hip (persistent, filter resident in LDS)
   int dma;               // 1: conv_dma_kernel (filter chunks by LDS-DMA, double buffered)
+  int xk;                // conv_dma_kernel: channels per staged input chunk
   int WM, WN, XMAX;      // narrow kernel template selection
   int first;             // 1: conv_first.hip (3 -> 8 channel first layer on the vector ALU)
 };

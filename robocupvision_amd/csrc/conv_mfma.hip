@@ -29,6 +29,7 @@
 // epilogue adds bias / skip gradient, applies ReLU, stores, and emits the per-tile partial sums the
 // following BatchNorm (forward or backward) needs -- fixed order, no atomics.
 #include <stdlib.h>
+#include <type_traits>
 #include "conv_common.h"
 
 // Stage the [IH*IW][CK] input tile of channel chunk c0 into xl ([pixel][CK+1]); UNR independent 16-byte
@@ -425,11 +426,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_mfma_kernel(const 
 typedef __attribute__((address_space(3))) void* rcv_lds_ptr;
 typedef const __attribute__((address_space(1))) void* rcv_glb_ptr;
 
+#ifdef RCV_STAMPS
+// diagnostic build only (make STAMPS=1): shader-clock stamps around the segments of the pipelined loop, summed per wave
+#define RCV_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RCV_STAMP(t) do { } while (0)
+#endif
+
 template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND, bool TWO>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const ConvArgs a) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int NW = NT / 64;
   constexpr int COT = WM * WAVES_M * 16;
-  constexpr int CK = 4;
+  constexpr int CK = 4;                         // channels per pipeline step (one k-step of the MFMA)
   const int S = a.xpitch;
   constexpr int WS = COT;                       // unpadded rows: the DMA image is lane-linear
   constexpr int C4 = COT / 4;
@@ -448,9 +457,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int npix = a.IH * a.IW;
-
-  if (a.in_c && a.in_mode != RCV_LOAD_PLAIN && a.in_mode != RCV_LOAD_NCHW)
-    for (int e = tid; e < 5 * a.Cin; e += NT) cl[e] = a.in_c[e];
+  // The input tile is staged XK (8 or 16) channels at a time, i.e. once per XSTEPS pipeline steps: a thread owns one 16-byte quad of
+  // one pixel per slot, so a pixel's XK channels are one contiguous 32/64-byte piece of its NHWC record and the address arithmetic,
+  // the load transform and its constants are paid once per XK/4 steps instead of every step.
+  const int XK = a.xk, xq_shift = XK == 16 ? 2 : 1, XQ = 1 << xq_shift, XSTEPS = XK / CK;
+  const int xtotal = npix << xq_shift;          // (pixel, quad) items of one input chunk; <= XMAX * NT (host)
 
   const TileInfo ti = decode_tile<KIND>(a, xcd_remap(blockIdx.x, a.total_tiles), COT);
   int nxt = 3, ntaps = 9;
@@ -460,71 +471,94 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   const int IS = KIND == KIND_GATHER ? a.stride : 1;
   const int wtotal = ntaps * CK * C4;           // 16-byte pieces of one filter chunk (a multiple of 64 for COT >= 64)
 
-  auto dma_w = [&](int buf, int c0) {
+  // ---- filter stream: per wave-instruction u one lane-constant source offset (floats, chunk 0) and one LDS destination.  The image
+  // is lane-linear ([tap][k][COT], as the DMA writes it) but the SOURCE is free per lane: rows with odd k take their 16-channel
+  // blocks pairwise swapped (quad index ^ 4), and the A-operand read below applies the same swap.  The rows k and k+1 that the two
+  // k-lanes of a 32-lane LDS access group read then sit 16 banks apart instead of on the same 16 banks (2-way conflict on every A read).
+  int woff[WU];
+  int wdst[WU];
 #pragma unroll
-    for (int u = 0; u < WU; ++u) {
-      int e0 = (u * (NT / 64) + wave) * 64;                 // first piece of this wave-instruction (wave uniform)
-      if (e0 + 64 > wtotal) e0 = wtotal - 64;               // every wave issues exactly WU instructions (a duplicate piece rewrites the
-      {                                                     // same bytes): the counted s_waitcnt of the pipelined loop relies on it
-        const int e = e0 + lane;
-        const int row = e / C4, c4 = e % C4;
-        const int j = row / CK, ck = row % CK;
-        int t9 = j;
-        if (KIND == KIND_TPHASE) {
-          const int jy = j / nxt, jx = j - jy * nxt;
-          const int ky = ti.py ? (jy ? 2 : 0) : 1;
-          const int kx = ti.px ? (jx ? 2 : 0) : 1;
-          t9 = ky * 3 + kx;
-        }
-        const float* src = a.w + ((size_t)(t9 * a.CinP + c0 + ck) * a.CoutP + ti.co0 + 4 * c4);
-        float* dst = wl + buf * WBUF + e0 * 4;              // + lane*16 B is added by the hardware
-        __builtin_amdgcn_global_load_lds((rcv_glb_ptr)src, (rcv_lds_ptr)dst, 16, 0, 0);
-      }
+  for (int u = 0; u < WU; ++u) {
+    int e0 = (u * NW + __builtin_amdgcn_readfirstlane(wave)) * 64;   // first piece of this wave-instruction (a scalar)
+    if (e0 + 64 > wtotal) e0 = wtotal - 64;                 // past the end: repeat the last pieces (same bytes) -- every wave issues exactly WU
+    const int e = e0 + lane;                                // instructions per step, branch-free
+    const int row = e / C4, c4 = (e % C4) ^ ((row & 1) << 2);
+    const int j = row / CK, ck = row % CK;
+    int t9 = j;
+    if (KIND == KIND_TPHASE) {
+      const int jy = j / nxt, jx = j - jy * nxt;
+      const int ky = ti.py ? (jy ? 2 : 0) : 1;
+      const int kx = ti.px ? (jx ? 2 : 0) : 1;
+      t9 = ky * 3 + kx;
     }
+    woff[u] = (t9 * a.CinP + ck) * a.CoutP + ti.co0 + 4 * c4;
+    wdst[u] = e0 * 4;
+  }
+  auto dma_one = [&](int buf, int step, int u) {
+    const float* wsrc = a.w + (size_t)step * CK * a.CoutP;
+    float* dst = wl + buf * WBUF + wdst[u];                 // + lane*16 B is added by the hardware
+    __builtin_amdgcn_global_load_lds((rcv_glb_ptr)(wsrc + woff[u]), (rcv_lds_ptr)dst, 16, 0, 0);
+  };
+  auto dma_w = [&](int buf, int step) {
+#pragma unroll
+    for (int u = 0; u < WU; ++u) dma_one(buf, step, u);
   };
 
+  // ---- input stream: registers -> (load transform) -> xl[g & 1] as [pixel][XK + pad]
   float4 px[XMAX], pa[AMAX];
-  uint32_t okmask = 0;
-  auto load_x = [&](int c0) {
-    okmask = 0;
+  int xsrc[XMAX];                                // element offset of (pixel, quad) in the NHWC tensor, channel chunk 0; < 0: outside the plane
 #pragma unroll
-    for (int u = 0; u < XMAX; ++u) {
-      const int pix = tid + u * NT;
-      const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
-      const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
-      // branch-free (an invalid slot reads element c0 of pixel 0 and is masked in write_x): a fixed number of load instructions per
-      // wave keeps the compiler's and our own counted waits exact
-      const bool ok = pix < npix && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      okmask |= (ok ? 1u : 0u) << u;
-      const size_t off = (ok ? ((size_t)(ti.n * a.H + gy) * a.W + gx) * a.Cin : 0) + c0;
+  for (int u = 0; u < XMAX; ++u) {
+    const int idx = tid + u * NT;
+    const int pix = idx >> xq_shift, q = idx & (XQ - 1);
+    const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
+    const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
+    const bool ok = idx < xtotal && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    xsrc[u] = ok ? (((ti.n * a.H + gy) * a.W + gx) * a.Cin + 4 * q) : -1;      // (host: N*H*W*Cin < 2^31)
+  }
+  auto load_slot = [&](int g, int u) {
+    if (u * NT < xtotal) {                       // workgroup uniform: whole slots without items are skipped
+      // branch-free inside (an invalid item reads the chunk of element 0 and is masked in write_x)
+      const size_t off = (size_t)(xsrc[u] >= 0 ? xsrc[u] : 0) + g * XK;
       px[u] = ld4(a.in + off);
       if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
     }
   };
-  auto write_x = [&](int buf, int c0) {
-    float* xb = xl + buf * a.xl_floats;
-    float4 k[5];
-    if (a.in_mode != RCV_LOAD_PLAIN) {
+  auto load_x = [&](int g) {
 #pragma unroll
-      for (int j = 0; j < 5; ++j) k[j] = *reinterpret_cast<const float4*>(cl + j * a.Cin + c0);
+    for (int u = 0; u < XMAX; ++u) load_slot(g, u);
+  };
+  auto write_x_mode = [&](auto mode_c, int buf, int g) {
+    constexpr int MODE = decltype(mode_c)::value;
+    float* xb = xl + buf * a.xl_floats;
+    const int q = tid & (XQ - 1);                // NT is a multiple of XQ: the quad of a thread is the same in every slot
+    float4 k[5];
+    if (MODE != RCV_LOAD_PLAIN) {
+      constexpr int NK = (MODE == RCV_LOAD_AFFINE || MODE == RCV_LOAD_AFFINE_RELU) ? 2 : (MODE == RCV_LOAD_GRAD_ENC ? 3 : 5);
+#pragma unroll
+      for (int j = 0; j < NK; ++j) k[j] = *reinterpret_cast<const float4*>(cl + j * a.Cin + g * XK + 4 * q);
     }
 #pragma unroll
     for (int u = 0; u < XMAX; ++u) {
-      const int pix = tid + u * NT;
-      if (pix < npix) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((okmask >> u) & 1u) {
-          switch (a.in_mode) {
-            case RCV_LOAD_PLAIN: v = px[u]; break;
-            case RCV_LOAD_AFFINE: v = xform4<RCV_LOAD_AFFINE>(px[u], px[u], k); break;
-            case RCV_LOAD_AFFINE_RELU: v = xform4<RCV_LOAD_AFFINE_RELU>(px[u], px[u], k); break;
-            case RCV_LOAD_GRAD_ENC: v = xform4<RCV_LOAD_GRAD_ENC>(px[u], pa[TWO ? u : 0], k); break;
-            default: v = xform4<RCV_LOAD_GRAD_DEC>(px[u], pa[TWO ? u : 0], k); break;
-          }
+      if (u * NT < xtotal) {
+        const int idx = tid + u * NT;
+        if (idx < xtotal) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (xsrc[u] >= 0) v = xform4<MODE>(px[u], pa[TWO ? u : 0], k);   // zero padding AFTER the transform
+          float* d = xb + (idx >> xq_shift) * S + 4 * q;
+          d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
-        float* d = xb + pix * S;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
       }
+    }
+  };
+  auto write_x = [&](int buf, int g) {
+    if constexpr (TWO) {
+      if (a.in_mode == RCV_LOAD_GRAD_ENC) write_x_mode(std::integral_constant<int, RCV_LOAD_GRAD_ENC>{}, buf, g);
+      else write_x_mode(std::integral_constant<int, RCV_LOAD_GRAD_DEC>{}, buf, g);
+    } else {
+      if (a.in_mode == RCV_LOAD_AFFINE) write_x_mode(std::integral_constant<int, RCV_LOAD_AFFINE>{}, buf, g);
+      else if (a.in_mode == RCV_LOAD_AFFINE_RELU) write_x_mode(std::integral_constant<int, RCV_LOAD_AFFINE_RELU>{}, buf, g);
+      else write_x_mode(std::integral_constant<int, RCV_LOAD_PLAIN>{}, buf, g);
     }
   };
 
@@ -536,7 +570,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
     if (ty >= a.R) { ty = 0; tx = 0; }
     pixoff[b] = ((ty * IS) * a.IW + tx * IS) * S + l4;
   }
-  const int aoff = l4 * WS + (wave_m * WM) * 16 + l15;
+  int aoff[WM];                                 // A operand: filter row k = l4, column block swapped on odd rows (see dma_w)
+#pragma unroll
+  for (int m = 0; m < WM; ++m) aoff[m] = l4 * WS + ((((wave_m * WM + m) * 16) + l15) ^ ((l4 & 1) << 4));
 
   f32x4 acc[NPH][WM][WN];
 #pragma unroll
@@ -546,78 +582,154 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
 #pragma unroll
       for (int b = 0; b < WN; ++b) acc[ph][m][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const bool dbg_nostage = a.flags & RCV_F_DBG_NOSTAGE, dbg_nomfma = a.flags & RCV_F_DBG_NOMFMA;
-  const int nchunks = a.CinP / CK;
-  // Pipeline over the 4-channel chunks.  F(c) = filter slab of chunk c (LDS-DMA into wl[c&1]); X(c) = input chunk (registers, then
-  // transformed into xl[c&1]).  In iteration i the MFMAs of chunk i run in two halves; between them X(i+1), loaded one iteration
-  // earlier, is written to the other input buffer and X(i+2) is requested, so neither the load latency nor the transform sits between
-  // two contractions; F(i+1) is requested right after the barrier that retires buffer (i+1)&1.  One barrier per chunk.
-  constexpr int NX = XMAX * (TWO ? 2 : 1);          // vector-memory instructions of one X(c) per wave (branch-free => exact)
-  auto taps = [&](int buf, int j0, int j1) {
-    const float* wb = wl + buf * WBUF;
-    const float* xb = xl + buf * a.xl_floats;
-    auto tap = [&](int j, int dy, int dx, int ph) {
-      const float* wj = wb + j * CK * WS + aoff;
-      const float* xj = xb + (dy * a.IW + dx) * S;
-      float av[WM], bv[WN];
+  const int nsteps = a.CinP / CK, ngroups = a.CinP / XK;
+#ifdef RCV_STAMPS
+  unsigned long long st_k0 = 0, st_a = 0, st_b = 0, st_seg[6] = {0, 0, 0, 0, 0, 0}, st_loop0 = 0, st_loop1 = 0, st_rt0 = __builtin_amdgcn_s_memrealtime();
+  RCV_STAMP(st_k0);
+#endif
+  // Pipeline over the 4-channel steps.  F(i) = filter slab of step i (LDS-DMA into wl[i & 1], requested one step ahead);
+  // X(g) = input chunk of group g = steps [g XSTEPS, (g+1) XSTEPS), in xl[g & 1]: loaded into registers in the first step of group g-1
+  // and written (transformed) between the two MFMA halves of that group's second step, so neither the load latency nor the
+  // transform sits between two contractions.  One barrier per step; everything a step waits for was requested a whole step earlier.
+  // The operands of tap j+1 are read from LDS ahead of the MFMAs of tap j (two register sets).
+  struct Ops { float av[WM]; float bv[WN]; };
+  auto read_tap = [&](Ops& o, const float* wb, const float* xb, int j, int dy, int dx) {
+    const float* wj = wb + j * CK * WS;
+    const float* xj = xb + (dy * a.IW + dx) * S;
 #pragma unroll
-      for (int m = 0; m < WM; ++m) av[m] = wj[m * 16];
+    for (int m = 0; m < WM; ++m) o.av[m] = wj[aoff[m]];
 #pragma unroll
-      for (int b = 0; b < WN; ++b) bv[b] = xj[pixoff[b]];
+    for (int b = 0; b < WN; ++b) o.bv[b] = xj[pixoff[b]];
+  };
+  auto mfma_tap = [&](const Ops& o, int ph) {
 #pragma unroll
-      for (int m = 0; m < WM; ++m)
+    for (int m = 0; m < WM; ++m)
 #pragma unroll
-        for (int b = 0; b < WN; ++b)
-          acc[ph][m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[ph][m][b], 0, 0, 0);
-    };
-    if (KIND == KIND_GATHER) {
-#pragma unroll
-      for (int j = 0; j < 9; ++j)
-        if (j >= j0 && j < j1) tap(j, (j / 3) * a.dil, (j % 3) * a.dil, 0);
-    } else if (KIND == KIND_TALL) {
+      for (int b = 0; b < WN; ++b)
+        acc[ph][m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[m], o.bv[b], acc[ph][m][b], 0, 0, 0);
+  };
+  // tap j of this workgroup's schedule -> (dy, dx, accumulator set)
+  auto tap_geom = [&](int j, int& dy, int& dx, int& ph) {
+    ph = 0;
+    if (KIND == KIND_GATHER) { dy = (j / 3) * a.dil; dx = (j % 3) * a.dil; }
+    else if (KIND == KIND_TALL) {
       // filter tap (ky,kx) of ConvTranspose2d(k3,s2,p1,op1): output row 2y+py takes input row y+dy through ky:
       // py=0: (dy=0,ky=1); py=1: (dy=0,ky=2),(dy=1,ky=0) -- the same along x.  Nine taps, each into the accumulators of its parity.
-#pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        const int ky = j / 3, kx = j % 3;
-        const int py = ky == 1 ? 0 : 1, dy = ky == 0 ? 1 : 0, px = kx == 1 ? 0 : 1, dx = kx == 0 ? 1 : 0;
-        if (j >= j0 && j < j1) tap(j, dy, dx, NPH == 4 ? py * 2 + px : 0);
-      }
+      const int ky = j / 3, kx = j % 3;
+      const int py = ky == 1 ? 0 : 1, pxx = kx == 1 ? 0 : 1;
+      dy = ky == 0 ? 1 : 0; dx = kx == 0 ? 1 : 0;
+      ph = NPH == 4 ? py * 2 + pxx : 0;
     } else {
-      for (int j = j0; j < j1 && j < ntaps; ++j) {
-        const int jy = j / nxt, jx = j - jy * nxt;
-        if (KIND == KIND_TPHASE) tap(j, ti.py ? (jy ? 0 : 1) : 0, ti.px ? (jx ? 0 : 1) : 0, 0);
-        else tap(j, jy, jx, 0);
-      }
+      const int jy = j / nxt, jx = j - jy * nxt;
+      if (KIND == KIND_TPHASE) { dy = ti.py ? (jy ? 0 : 1) : 0; dx = ti.px ? (jx ? 0 : 1) : 0; }
+      else { dy = jy; dx = jx; }
     }
   };
-  if (!dbg_nostage) {
-    dma_w(0, 0);
-    load_x(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    write_x(0, 0);
-    if (nchunks > 1) load_x(CK);                     // X(1)
-  }
-  const int jsplit = (KIND == KIND_GATHER || KIND == KIND_TALL) ? 5 : (ntaps + 1) / 2;
-  for (int i = 0; i < nchunks; ++i) {
+
+  // ---- prologue: F(0), X(0) and the load constants are requested together (one memory round trip)
+  dma_w(0, 0);
+  load_x(0);
+  if (a.in_c && a.in_mode != RCV_LOAD_PLAIN)
+    for (int e = tid; e < 5 * a.Cin; e += NT) cl[e] = a.in_c[e];
+  __syncthreads();
+  write_x(0, 0);
+  constexpr int JSPLIT = (KIND == KIND_GATHER || KIND == KIND_TALL) ? 5 : 2;
+#ifdef RCV_STAMPS
+  RCV_STAMP(st_loop0);
+  st_a = st_loop0;
+#endif
+  for (int i = 0; i < nsteps; ++i) {
     const int buf = i & 1;
-    // F(i) must have landed; the only younger requests of this wave are the NX loads of X(i+1)
-    if (i + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // xl[buf] complete (written during iteration i-1), F(i) visible, buffers buf^1 retired by every wave.  A bare barrier: the fence
-    // of __syncthreads() would drain vmcnt(0), i.e. wait for the X(i+1) loads this pipeline wants to keep in flight
+    const int g = i / XSTEPS, sub = i - g * XSTEPS;
+    // F(i) (and X(g+1), if this is the second step of the group) have landed: they were requested a whole step ago
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // xl[g & 1] complete, F(i) visible to every wave, buffers of step i-1 retired.  A bare barrier (the LDS writes of this wave are
+    // waited for explicitly)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef RCV_STAMPS
+    RCV_STAMP(st_b); st_seg[0] += st_b - st_a; st_a = st_b;
+#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const bool more = i + 1 < nchunks && !dbg_nostage;
-    if (more) dma_w(buf ^ 1, (i + 1) * CK);           // F(i+1), lands during this iteration
-    if (!dbg_nomfma) taps(buf, 0, jsplit);
-    if (more) {
-      write_x(buf ^ 1, (i + 1) * CK);                 // the compiler waits for X(i+1) with a counted vmcnt (WU younger DMA requests)
-      if (i + 2 < nchunks) load_x((i + 2) * CK);      // X(i+2)
+#ifdef RCV_STAMPS
+    RCV_STAMP(st_b); st_seg[1] += st_b - st_a; st_a = st_b;
+#endif
+    // F(i+1) and X(g+1) are requested from inside the tap loop, one instruction per tap (an LDS-DMA instruction holds the wave's
+    // issue for 60..100 cycles: spread out, the matrix pipe keeps running behind each of them).  The last step re-requests its own
+    // slab into the retired buffer instead of branching.
+    const bool ldx = sub == 0 && g + 1 < ngroups;
+    const int fstep = i + 1 < nsteps ? i + 1 : i;
+    constexpr bool SPREAD = KIND == KIND_GATHER;   // (all-parity transposed conv, 5-MFMA taps: measured 10 % slower spread out)
+    if (!SPREAD) {
+      if (ldx) load_x(g + 1);
+      dma_w(buf ^ 1, fstep);
     }
-    if (!dbg_nomfma) taps(buf, jsplit, 9);
+#ifdef RCV_STAMPS
+    RCV_STAMP(st_b); st_seg[2] += st_b - st_a; st_a = st_b;
+#endif
+    const float* wb = wl + buf * WBUF;
+    const float* xb = xl + (g & 1) * a.xl_floats + sub * CK;
+    const bool wx = (sub == 1 || XSTEPS == 1) && g + 1 < ngroups;
+    if (KIND == KIND_GATHER || KIND == KIND_TALL) {
+      // Two operand register sets: the LDS reads of tap j+1 are issued one behind each of the first MFMAs of tap j (pinned with
+      // sched_group_barrier: left alone, the compiler sinks them to the end of the tap and every tap starts with an exposed LDS
+      // round trip: 84 % instead of ~97 % of the issue rate for a wave that has the matrix pipe to itself).
+      constexpr int N_M = WM * WN, N_D = WM + WN, N_PAIR = N_M < N_D ? N_M : N_D;
+      Ops o0, o1;
+      int dy, dx, ph, ph_next = 0;
+      tap_geom(0, dy, dx, ph);
+      read_tap(o0, wb, xb, 0, dy, dx);
+      if (N_M >= N_D + 2) __builtin_amdgcn_sched_group_barrier(0x100, N_D, 0);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        Ops& cur = (j & 1) ? o1 : o0;
+        Ops& nxt_ = (j & 1) ? o0 : o1;
+        if (j == JSPLIT) {
+#ifdef RCV_STAMPS
+          RCV_STAMP(st_b); st_seg[3] += st_b - st_a; st_a = st_b;
+#endif
+          if (wx) write_x((g + 1) & 1, g + 1);
+#ifdef RCV_STAMPS
+          RCV_STAMP(st_b); st_seg[4] += st_b - st_a; st_a = st_b;
+#endif
+        }
+        if (j + 1 < 9) { tap_geom(j + 1, dy, dx, ph_next); read_tap(nxt_, wb, xb, j + 1, dy, dx); }
+        if (SPREAD && j < WU) dma_one(buf ^ 1, fstep, j < WU ? j : 0);           // F(i+1), one LDS-DMA instruction per tap
+        if (SPREAD && j >= 9 - XMAX && ldx) load_slot(g + 1, j - (9 - XMAX));   // X(g+1): registers, written to LDS in the next step
+        mfma_tap(cur, ph);
+        ph = ph_next;
+        if (N_M < N_D + 2) {
+          // (5-MFMA taps of the all-parity transposed conv: pinning measured 8..14 % slower than the compiler's own order)
+        } else if (j + 1 < 9) {
+          if (N_D > N_PAIR) __builtin_amdgcn_sched_group_barrier(0x100, N_D - N_PAIR, 0);
+#pragma unroll
+          for (int k = 0; k < N_PAIR; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          if (N_M > N_PAIR) __builtin_amdgcn_sched_group_barrier(0x008, N_M - N_PAIR, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, N_M, 0);
+        }
+      }
+    } else {
+      Ops o;
+      int dy, dx, ph;
+      for (int j = 0; j < ntaps; ++j) {
+        if (j == JSPLIT && wx) write_x((g + 1) & 1, g + 1);
+        tap_geom(j, dy, dx, ph);
+        read_tap(o, wb, xb, j, dy, dx);
+        mfma_tap(o, 0);
+      }
+      if (ntaps <= JSPLIT && wx) write_x((g + 1) & 1, g + 1);
+    }
+#ifdef RCV_STAMPS
+    RCV_STAMP(st_b); st_seg[5] += st_b - st_a; st_a = st_b;
+#endif
   }
+#ifdef RCV_STAMPS
+  RCV_STAMP(st_loop1);
+#endif
   if (KIND == KIND_TALL) {
 #pragma unroll
     for (int ph = 0; ph < NPH; ++ph) {
@@ -627,8 +739,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
       conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND_TPHASE, 2>(a, tp, acc[ph], red, tid);   // 160 accumulator registers are live: small batches
     }
   } else {
-    conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND>(a, ti, acc[0], red, tid);
+    // data-gradient launches (TWO) carry a residual and a BN-backward operand per output element: requested in one batch
+    conv_epilogue<WM, WN, WAVES_M, WAVES_N, KIND, (TWO || WM == 1) ? WN : 0>(a, ti, acc[0], red, tid);
   }
+#ifdef RCV_STAMPS
+  if (a.stamps) {
+    unsigned long long st_end;
+    RCV_STAMP(st_end);
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      unsigned long long* o = a.stamps + ((size_t)blockIdx.x * (NT / 64) + wave) * 12;
+      o[0] = st_loop0 - st_k0; o[1] = st_loop1 - st_loop0; o[2] = st_end - st_loop1;
+      for (int k = 0; k < 6; ++k) o[3 + k] = st_seg[k];
+      o[9] = rt1 - st_rt0; o[10] = st_end - st_k0; o[11] = st_rt0;
+    }
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------
@@ -767,7 +893,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   // candidates by (virtual) output-channel count; minimise padded work, prefer the larger tile on ties
   // LDS-DMA filter streaming pays where the filter dominates the staged bytes (wide layers); with few input
   // channels its 4-channel chunks fragment the HBM-bound input reads instead
-  const bool use_dma = mode != RCV_LOAD_NCHW && Cin >= 64 && !getenv("RCV_NO_DMA");
+  const bool use_dma = mode != RCV_LOAD_NCHW && Cin >= 64 && CinP % 8 == 0 && (long long)N * H * W * Cin < (1ll << 31) && !getenv("RCV_NO_DMA");
   (void)Q;
   long best = -1;
   pl->tile = -1;
@@ -779,7 +905,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
     if (pl->CoutP >= 64 && cot < 32) continue;
     const bool tall5 = use_dma && t == 5 && pl->kind == KIND_TPHASE && !getenv("RCV_NO_TALL");     // 32-channel tile: only as KIND_TALL
     const bool dma_tile = (use_dma && (t == 0 || t == 1 || t == 4)) || tall5;
-    const int cap = dma_tile ? kTiles[t].nt() * 4 : 65535;      // DMA variant: input chunk rides in 4 registers per thread
+    const int cap = dma_tile ? kTiles[t].nt() * 2 : 65535;      // DMA variant: the input chunk (>= 8 channels = 2 quads per pixel) rides in 4 register slots per thread
     int R, Wt, tx, ty;
     if (!plan_tile(pl->kind, TH, TW, kTiles[t].pix(), s, d, cap, &R, &Wt, &tx, &ty)) continue;
     const long work = (long)tx * ty * kTiles[t].pix() * round_up(pl->CoutP, cot);
@@ -792,7 +918,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
     // 32-channel transposed conv with >= 64 input channels: the half-size tile runs as KIND_TALL on the LDS-DMA kernel
     // (64 -> 32 at 32x60x80: 0.100 instead of 0.140 ms)
     int R, Wt, tx, ty;
-    if (plan_tile(pl->kind, TH, TW, kTiles[5].pix(), s, d, kTiles[5].nt() * 4, &R, &Wt, &tx, &ty)) {
+    if (plan_tile(pl->kind, TH, TW, kTiles[5].pix(), s, d, kTiles[5].nt() * 2, &R, &Wt, &tx, &ty)) {
       pl->tile = 5; pl->R = R; pl->Wt = Wt; pl->tiles_x = tx; pl->tiles_y = ty;
     }
   }
@@ -803,7 +929,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
     if (sibling >= 0 && nwg < h->num_cus && !(pl->kind == KIND_TMERGED && kTiles[sibling].cot() < pl->CoutP)) {
       const bool dma_tile = use_dma && sibling == 4;
       int R, Wt, tx, ty;
-      if (plan_tile(pl->kind, TH, TW, kTiles[sibling].pix(), s, d, dma_tile ? kTiles[sibling].nt() * 4 : 65535, &R, &Wt, &tx, &ty)) {
+      if (plan_tile(pl->kind, TH, TW, kTiles[sibling].pix(), s, d, dma_tile ? kTiles[sibling].nt() * 2 : 65535, &R, &Wt, &tx, &ty)) {
         pl->tile = sibling; pl->R = R; pl->Wt = Wt; pl->tiles_x = tx; pl->tiles_y = ty;
       }
     }
@@ -819,12 +945,22 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   tile_halo(pl->kind, pl->R, pl->Wt, s, d, &pl->IH, &pl->IW);
   const int ntaps = pl->kind == KIND_GATHER ? 9 : 4;
   const bool tall5 = pl->tile == 5 && pl->kind == KIND_TPHASE && !getenv("RCV_NO_TALL");
-  pl->dma = use_dma && (pl->tile == 0 || pl->tile == 1 || pl->tile == 4 || tall5) && pl->IH * pl->IW <= tc.nt() * 4;
+  pl->dma = use_dma && (pl->tile == 0 || pl->tile == 1 || pl->tile == 4 || tall5) && pl->IH * pl->IW <= tc.nt() * 2;
+  pl->xk = 0;
   size_t floats;
   if (pl->dma) {
     pl->CK = 4;
+    const int taps_dma = (pl->kind == KIND_TPHASE && (pl->tile == 4 || pl->tile == 5) && !getenv("RCV_NO_TALL")) ? 9 : ntaps;   // KIND_TALL below
     pl->wl_floats = ntaps * 4 * tc.cot();
-    pl->xl_floats = round_up(pl->IH * pl->IW * conv_xpitch(4, pl->kind == KIND_GATHER ? s : 1), 4);
+    // input chunk: 16 channels per staging pass when the tile fits the register slots and leaves room for two workgroups per CU
+    // (the pipeline overlaps one workgroup's staging with the other's contraction), else 8
+    const int npix = pl->IH * pl->IW, xs = pl->kind == KIND_GATHER ? s : 1;
+    auto lds_floats = [&](int xk) {
+      return 2 * (size_t)taps_dma * 4 * tc.cot() + 2 * (size_t)round_up(npix * conv_xpitch(xk, xs), 4) + 5 * CinP + 16 + (size_t)tc.WAVES_N * 2 * tc.cot();
+    };
+    const size_t lds_room = (size_t)h->max_lds / 2;
+    pl->xk = (CinP % 16 == 0 && npix * 4 <= tc.nt() * 4 && lds_floats(16) * sizeof(float) <= lds_room) ? 16 : 8;
+    pl->xl_floats = round_up(npix * conv_xpitch(pl->xk, xs), 4);
     floats = 2 * (size_t)pl->wl_floats + 2 * (size_t)pl->xl_floats + 5 * CinP + 16 + (size_t)tc.WAVES_N * 2 * tc.cot();
   } else {
     pl->wl_floats = round_up(ntaps * pl->CK * (tc.cot() + 16), 4);
@@ -893,8 +1029,12 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   a.total_tiles = pl.total_tiles; a.nchunks = a.CinP / pl.CK;
   a.in_mode = op->i[RCV_I_INMODE]; a.stats = op->i[RCV_I_STATS]; a.flags = op->flags;
   a.wl_floats = pl.wl_floats; a.xl_floats = pl.xl_floats;
-  a.xpitch = conv_xpitch(pl.CK, pl.kind == KIND_GATHER ? a.stride : 1);
+  a.xk = pl.xk;
+  a.xpitch = conv_xpitch(pl.dma ? pl.xk : pl.CK, pl.kind == KIND_GATHER ? a.stride : 1);
   a.fdWt = make_fastdiv(pl.Wt); a.fdIW = make_fastdiv(pl.IW);
+#ifdef RCV_STAMPS
+  a.stamps = (unsigned long long*)op->p[RCV_P_X5];
+#endif
   RCV_CHECK_ARG(a.in && a.w && a.out, "conv: null operand");
   RCV_CHECK_ARG(a.in_mode == RCV_LOAD_PLAIN || a.in_mode == RCV_LOAD_NCHW || a.in_c, "conv: load mode %d needs constants", a.in_mode);
   RCV_CHECK_ARG(!(a.in_mode == RCV_LOAD_GRAD_ENC || a.in_mode == RCV_LOAD_GRAD_DEC) || a.in_aux, "conv: gradient load needs aux tensor");

@@ -22,6 +22,7 @@ ap.add_argument("--mode", default="affine"); ap.add_argument("--mode2", default=
 ap.add_argument("--stats", default="none"); ap.add_argument("--merged", type=int, default=0)
 ap.add_argument("--resid", type=int, default=0); ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--flags", type=int, default=0)
+ap.add_argument("--stamps", type=int, default=0, help="diagnostic library build (make STAMPS=1): print the per-segment cycle shares of conv_dma_kernel")
 a = ap.parse_args()
 dev = torch.device("cuda:0"); h = L.handle(0)
 N, H, W, Cin, Cout, s, d = a.N, a.H, a.W, a.Cin, a.Cout, a.stride, a.dil
@@ -60,6 +61,10 @@ else:
                    p_in2_aux=Pa.data_ptr(), p_in2_c=Pc.data_ptr())
     flops = 2.0 * 9 * Cin * Cout * N * Ho * Wo
     nbytes = 4.0 * (N * H * W * Cin * (2 if a.mode.startswith("grad") else 1) + N * Ho * Wo * Cout * (2 if a.mode2.startswith("grad") else 1))
+stamps = None
+if a.stamps:
+    stamps = torch.zeros(8192 * 8 * 12, dtype=torch.int64, device=dev)
+    op.p[L.RCV_P_X5] = stamps.data_ptr()
 nb = L.op_workspace(h, op)
 part = torch.empty(max(nb // 4, 4), device=dev)
 op.p[L.RCV_P_PART] = part.data_ptr()
@@ -72,3 +77,15 @@ torch.cuda.synchronize()
 ms = sum(lst.run_timed(h, st)[0] for _ in range(a.reps)) / a.reps
 print("%-26s %s N%d %dx%d %d->%d s%d mode=%s stats=%s merged=%d tile=%s flags=%x : %.4f ms  %.2f TF/s  %.1f GB/s" %
       (label, a.kind, N, H, W, Cin, Cout, s, a.mode, a.stats, a.merged, os.environ.get("RCV_CONV_TILE", "-"), flags, ms, flops / ms / 1e9, nbytes / ms / 1e6))
+
+if stamps is not None:
+    torch.cuda.synchronize()
+    st = stamps.view(-1, 12).cpu().double()
+    st = st[st[:, 10] > 0]
+    names = ["prologue", "loop", "epilogue", "wait_vm_lgkm", "barrier", "dma_issue", "taps0-5", "write_x+load_x", "taps5-9", "realtime(10ns)", "kernel_cycles"]
+    tot = st[:, 10].mean()
+    print("waves %d; mean shader cycles per wave %.0f; shader clock %.2f GHz" % (st.shape[0], tot, (st[:, 10] / (st[:, 9] * 10.0)).mean()))
+    for k, nm in enumerate(names[:9]):
+        print("  %-16s mean %9.0f (%5.1f%%)  min %9.0f  max %9.0f" % (nm, st[:, k].mean(), 100 * st[:, k].mean() / tot, st[:, k].min(), st[:, k].max()))
+    t0 = st[:, 11]
+    print("  start skew (10 ns ticks): min %.0f max %.0f" % (0, (t0.max() - t0.min())))
