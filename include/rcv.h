@@ -46,6 +46,9 @@ extern "C" {
 typedef struct rcv_handle rcv_handle;
 
 int  rcv_create(int device, rcv_handle** out);
+/* A handle without a device, for hosts that only lay out buffers: rcv_op_workspace / rcv_op_kernel_label answer for a chip with
+ * `num_cus` compute units (256 on MI355X); every call that would enqueue work fails with RCV_E_ARG. */
+int  rcv_create_planner(int num_cus, rcv_handle** out);
 int  rcv_destroy(rcv_handle* h);
 const char* rcv_last_error(void);
 int  rcv_version(void);
@@ -124,9 +127,11 @@ enum {
 #define RCV_F_SIDE_STREAM (1u << 16) /* rcv_run: enqueue this op on the handle's side stream (forked from / joined to the caller's
                                       * stream inside the call): ops off the critical path, e.g. the filter gradients of backward */
 #define RCV_F_CONCAT    256u  /* COMBINE: out[..,0:C] = relu(t*s+h), out[..,C:2C] = f(r)  (v2 skip concat, model.py:507) */
-#define RCV_F_DBG_NOSTAGE (1u << 20) /* profiling ablation: skip the global->LDS input staging (results are garbage) */
-#define RCV_F_DBG_NOSKIP  (1u << 22) /* profiling ablation: merged transposed conv without skipping the structurally zero filter blocks */
-#define RCV_F_DBG_NOMFMA  (1u << 21) /* profiling ablation: skip the MFMA contraction (results are garbage)          */
+/* bits 20..22: profiling ablations of diagnostic builds (skip staging / skip the contraction); the shipped kernels of the wide
+ * layers ignore them */
+#define RCV_F_DBG_NOSTAGE (1u << 20)
+#define RCV_F_DBG_NOSKIP  (1u << 22)
+#define RCV_F_DBG_NOMFMA  (1u << 21)
 
 /* integer slots */
 enum {
@@ -175,7 +180,8 @@ typedef struct rcv_op {
  * the bytes of the `part` workspace the op needs (0 if none). */
 int rcv_op_workspace(const rcv_handle* h, rcv_op* op, size_t* part_bytes);
 
-/* Enqueue ops[0..n) in order on `stream`. */
+/* Enqueue ops[0..n) in order on `stream`.  The handle's device is made current for the duration of the call (and the caller's
+ * current device restored): `stream` must belong to the handle's device. */
 int rcv_run(rcv_handle* h, const rcv_op* ops, int n, void* stream);
 
 /* rcv_run with options.  RCV_RUN_NO_JOIN: leave the side stream (RCV_F_SIDE_STREAM ops) un-joined when the call returns; the caller
@@ -269,9 +275,16 @@ int rcv_confusion(rcv_handle* h, const uint8_t* argmax, const int64_t* target, i
 int rcv_sgd_step(rcv_handle* h, float* param, const float* grad, float* momentum_buf, const float* lr_elem /*may be NULL*/,
                  int64_t n, float lr, float momentum, float weight_decay, int step, float grad_scale, void* stream);
 
+/* lr_elem (may be NULL): per-element learning rate; 0 = the element is not stepped at all (a parameter without a gradient).
+ * As an op record, p[RCV_P_X5] (may be NULL) is the prune mask of train.py:59-65 (`param.grad[indices] = 0` after backward):
+ * uint8 per element of the flat buffer, non-zero = the whole gradient of that element (L1 part included) is zero this step. */
 int rcv_adam_l1_step(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                      const float* lr_elem /*may be NULL*/, int64_t n, float lr, float beta1, float beta2,
                      float eps, float decay, int step, float grad_scale, void* stream);
+/* the same with the prune mask (rcv_adam_l1_step passes NULL) */
+int rcv_adam_l1_step_pruned(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                            const float* lr_elem /*may be NULL*/, const uint8_t* prune_mask /*may be NULL*/, int64_t n, float lr,
+                            float beta1, float beta2, float eps, float decay, int step, float grad_scale, void* stream);
 
 /* The same step, which also books the iteration's metrics (train.py:52-53,69-73) in the same launch:
  * metrics[4] (double, device) += { loss_stats[0] + decay*sum|p|, decay*sum|p|, loss_stats[2], 1 } with sum|p| taken before

@@ -195,17 +195,39 @@ class TrainState:
         return [self.sd[n] for n in self.names]
 
 
-def train_step(st: TrainState, imgs: Tensor, targets: Tensor, do_step: bool = True) -> Dict[str, object]:
-    """train.py:43-74 (no prune indices): zero_grad, fwd, CE + decay*L1, backward, Adam, argmax."""
+def prune_model_new(params: Sequence[Tensor], ratio: float = 0.01) -> List[Tensor]:
+    """model.py:45-57: per parameter with dim() > 1, zero the weights below ratio*max|w| and return the masks."""
+    indices = []
+    with torch.no_grad():
+        for param in params:
+            if param.dim() > 1:
+                thresh = torch.max(torch.abs(param)) * ratio
+                param[torch.abs(param) < thresh] = 0
+                indices.append(torch.abs(param) < thresh)
+    return indices
+
+
+def train_step(st: TrainState, imgs: Tensor, targets: Tensor, do_step: bool = True, indices=None) -> Dict[str, object]:
+    """train.py:43-74: zero_grad, fwd, CE (+ decay*L1 unless pruning), backward, (gradients of pruned weights zeroed), Adam, argmax."""
     st.opt.zero_grad()
     pred = robo_unet_forward(st.sd, imgs, st.cfg, training=True)
     if st.use_dice:
         ce = dice_loss(pred, targets, dice_weights(st.ce_weight))
     else:
         ce = cross_entropy_2d(pred, targets, st.ce_weight)
-    reg = st.decay * l1reg(st.params())
-    loss = ce + reg
+    reg = torch.zeros(())
+    loss = ce
+    if indices is None:                      # train.py:52-55
+        reg = st.decay * l1reg(st.params())
+        loss = ce + reg
     loss.backward()
+    if indices is not None:                  # train.py:59-65
+        pIdx = 0
+        for param in st.params():
+            if param.dim() > 1:
+                if param.grad is not None:
+                    param.grad[indices[pIdx]] = 0
+                pIdx += 1
     if do_step:
         st.opt.step()
     _, pred_class = torch.max(pred, 1)

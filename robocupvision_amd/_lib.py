@@ -44,7 +44,7 @@ EXPORTS = [
     "rcv_run_timed", "rcv_op_kernel_label", "rcv_run_ex", "rcv_join_side",
     "rcv_conv3x3", "rcv_convT3x3s2", "rcv_wgrad3x3", "rcv_bn_finalize", "rcv_bn_backward", "rcv_maxpool2x2_fwd",
     "rcv_softmax_ce_argmax_fwd", "rcv_softmax_ce_bwd", "rcv_adam_l1_step", "rcv_adam_l1_step_metrics", "rcv_confusion",
-    "rcv_dice_fwd", "rcv_dice_bwd", "rcv_sgd_step",
+    "rcv_dice_fwd", "rcv_dice_bwd", "rcv_sgd_step", "rcv_create_planner", "rcv_adam_l1_step_pruned",
 ]
 
 
@@ -71,6 +71,7 @@ def load():
         lib = C.CDLL(LIB_PATH)
         lib.rcv_last_error.restype = C.c_char_p
         lib.rcv_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        lib.rcv_create_planner.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         lib.rcv_destroy.argtypes = [C.c_void_p]
         lib.rcv_num_cus.argtypes = [C.c_void_p]
         lib.rcv_op_workspace.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.POINTER(C.c_size_t)]
@@ -100,6 +101,19 @@ def handle(device_index: int):
         check(lib.rcv_create(device_index, C.byref(out)), "rcv_create")
         h = out
         _handles[device_index] = h
+    return h
+
+
+def planner_handle(num_cus: int = 256):
+    """A handle without a device (rcv_create_planner): buffer layout / workspace queries only.  Used to lower a graph to its op
+    lists on a host without a GPU (tests of the data-parallel bucket logic); every call that would enqueue work fails."""
+    lib = load()
+    h = _handles.get(("planner", num_cus))
+    if h is None:
+        out = C.c_void_p()
+        check(lib.rcv_create_planner(num_cus, C.byref(out)), "rcv_create_planner")
+        h = out
+        _handles[("planner", num_cus)] = h
     return h
 
 

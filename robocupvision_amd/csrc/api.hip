@@ -13,6 +13,28 @@ void rcv_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Every entry point that creates streams / events or launches kernels makes the handle's device current for the duration of the
+// call and restores the caller's device afterwards (a process that drives cuda:1 while cuda:0 is current would otherwise get its
+// side stream, its events and its kernel launches on the wrong GPU).
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    if (dev < 0) return;
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define RCV_GUARD(h, what)                                                                                            \
+  RCV_CHECK_ARG((h)->device >= 0, what ": this is a planning-only handle (rcv_create_planner); it cannot enqueue work"); \
+  DeviceGuard guard_((h)->device);                                                                                    \
+  if (guard_.err != hipSuccess) { rcv_set_error(what ": cannot make device %d current: %s", (h)->device, hipGetErrorString(guard_.err)); return RCV_E_HIP; }
+
 extern "C" {
 
 const char* rcv_last_error(void) { return g_err; }
@@ -33,6 +55,23 @@ int rcv_create(int device, rcv_handle** out) {
   h->device = device;
   h->num_cus = prop.multiProcessorCount;
   h->max_lds = 160 * 1024;
+  h->plans = new rcv_plan_cache;
+  h->side_stream = nullptr;
+  h->ev_join = nullptr;
+  h->ev_next = 0;
+  for (auto& e : h->ev_fork) e = nullptr;
+  *out = h;
+  return RCV_OK;
+}
+
+int rcv_create_planner(int num_cus, rcv_handle** out) {
+  RCV_CHECK_ARG(out != nullptr, "rcv_create_planner: out is NULL");
+  RCV_CHECK_ARG(num_cus > 0 && num_cus <= 4096, "rcv_create_planner: num_cus %d out of range", num_cus);
+  rcv_handle* h = new rcv_handle;
+  h->device = -1;
+  h->num_cus = num_cus;
+  h->max_lds = 160 * 1024;
+  h->plans = new rcv_plan_cache;
   h->side_stream = nullptr;
   h->ev_join = nullptr;
   h->ev_next = 0;
@@ -43,10 +82,12 @@ int rcv_create(int device, rcv_handle** out) {
 
 int rcv_destroy(rcv_handle* h) {
   if (h && h->side_stream) {
+    DeviceGuard guard(h->device);
     (void)hipStreamDestroy(h->side_stream);
     (void)hipEventDestroy(h->ev_join);
     for (auto& e : h->ev_fork) (void)hipEventDestroy(e);
   }
+  if (h) delete h->plans;
   delete h;
   return RCV_OK;
 }
@@ -89,6 +130,7 @@ int rcv_run_ex(rcv_handle* h, const rcv_op* ops, int n, void* stream, uint32_t r
 int rcv_join_side(rcv_handle* h, void* stream) {
   RCV_CHECK_ARG(h, "rcv_join_side: NULL handle");
   if (!h->side_stream) return RCV_OK;         // nothing was ever forked
+  RCV_GUARD(h, "rcv_join_side");
   RCV_HIP(hipEventRecord(h->ev_join, h->side_stream));
   RCV_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0));
   return RCV_OK;
@@ -98,6 +140,7 @@ int rcv_join_side(rcv_handle* h, void* stream) {
 
 static int run_ops(rcv_handle* h, const rcv_op* ops, int n, void* stream, bool join) {
   RCV_CHECK_ARG(h && (ops || n == 0) && n >= 0, "rcv_run: bad arguments");
+  RCV_GUARD(h, "rcv_run");
   hipStream_t s = (hipStream_t)stream;
   // Ops flagged RCV_F_SIDE_STREAM run on the handle's side stream: it is forked from `stream` in front of every run of such ops
   // (event record on `stream`, wait on the side stream) and joined back before rcv_run returns, so the caller keeps seeing ONE
@@ -150,6 +193,7 @@ int rcv_op_kernel_label(const rcv_handle* h, const rcv_op* op, char* buf, int si
 
 int rcv_run_timed(rcv_handle* h, const rcv_op* ops, int n, void* stream, float* ms) {
   RCV_CHECK_ARG(h && ops && n > 0 && ms, "rcv_run_timed: bad arguments");
+  RCV_GUARD(h, "rcv_run_timed");
   hipStream_t s = (hipStream_t)stream;
   hipEvent_t* ev = new hipEvent_t[n + 1];
   for (int k = 0; k <= n; ++k) {
@@ -305,6 +349,20 @@ int rcv_adam_l1_step(rcv_handle* h, float* param, const float* grad, float* exp_
   op.f[0] = lr; op.f[1] = beta1; op.f[2] = beta2; op.f[3] = eps; op.f[4] = decay; op.f[5] = grad_scale;
   op.p[RCV_P_IN] = param; op.p[RCV_P_IN2] = (void*)grad; op.p[RCV_P_X0] = exp_avg; op.p[RCV_P_X1] = exp_avg_sq;
   op.p[RCV_P_X2] = (void*)lr_elem;
+  return rcv_run(h, &op, 1, stream);
+}
+
+int rcv_adam_l1_step_pruned(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* lr_elem,
+                            const uint8_t* prune_mask, int64_t n, float lr, float beta1, float beta2, float eps, float decay, int step,
+                            float grad_scale, void* stream) {
+  RCV_CHECK_ARG(n > 0 && n < 2147483647LL, "rcv_adam_l1_step_pruned: n out of range");
+  rcv_op op;
+  memset(&op, 0, sizeof(op));
+  op.kind = RCV_OP_ADAM_L1;
+  op.i[RCV_I_COUNT] = (int)n; op.i[RCV_I_AUX0] = step;
+  op.f[0] = lr; op.f[1] = beta1; op.f[2] = beta2; op.f[3] = eps; op.f[4] = decay; op.f[5] = grad_scale;
+  op.p[RCV_P_IN] = param; op.p[RCV_P_IN2] = (void*)grad; op.p[RCV_P_X0] = exp_avg; op.p[RCV_P_X1] = exp_avg_sq;
+  op.p[RCV_P_X2] = (void*)lr_elem; op.p[RCV_P_X5] = (void*)prune_mask;
   return rcv_run(h, &op, 1, stream);
 }
 

@@ -97,6 +97,7 @@ struct ConvPlan {
   int xk;                // conv_dma_kernel: channels per staged input chunk
   int WM, WN, XMAX;      // narrow kernel template selection
   int first;             // 1: conv_first.hip (3 -> 8 channel first layer on the vector ALU)
+  int dev;               // device of the handle the plan belongs to (per-device kernel attributes)
 };
 
 // LDS pitch of a staged input pixel holding CK channels.  The B operand of v_mfma_f32_16x16x4_f32 is read with ds_read_b32 at

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const ConvArgs a, int t
 // host side
 // --------------------------------------------------------------------------------------------
 bool conv_first_supported(const rcv_op* op, int kind) {
-  if (getenv("RCV_NO_CONV_FIRST")) return false;
+  if (RCV_ENV("RCV_NO_CONV_FIRST")) return false;
   const int d = op->i[RCV_I_DIL], st = op->i[RCV_I_STATS];
   return kind == KIND_GATHER && op->i[RCV_I_INMODE] == RCV_LOAD_NCHW && op->i[RCV_I_CIN] <= 4 && op->i[RCV_I_COUT] == 8 &&
          op->i[RCV_I_STRIDE] == 1 && (d == 1 || d == 2) && (st == RCV_STATS_NONE || st == RCV_STATS_FWD) && !(op->flags & RCV_F_RESID);

@@ -761,23 +761,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
 // Host side: tiling choice and launch
 // --------------------------------------------------------------------------------------------
 template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND>
-static int launch_dma(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+static int launch_dma(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, int dev) {
   const bool two = a.in_mode == RCV_LOAD_GRAD_ENC || a.in_mode == RCV_LOAD_GRAD_DEC;
   if (two) {
     auto kern = conv_dma_kernel<WM, WN, WAVES_M, WAVES_N, KIND, true>;
-    static size_t configured = 0;
-    if (lds > configured) {
-      RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = lds;
-    }
+    static size_t configured[RCV_MAX_DEVICES];
+    RCV_ENSURE_LDS(kern, lds, dev, configured);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, a);
   } else {
     auto kern = conv_dma_kernel<WM, WN, WAVES_M, WAVES_N, KIND, false>;
-    static size_t configured = 0;
-    if (lds > configured) {
-      RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = lds;
-    }
+    static size_t configured[RCV_MAX_DEVICES];
+    RCV_ENSURE_LDS(kern, lds, dev, configured);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, a);
   }
   RCV_HIP(hipGetLastError());
@@ -785,11 +779,11 @@ static int launch_dma(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
 }
 
 template <int KIND>
-static int launch_dma_tile(int tile, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+static int launch_dma_tile(int tile, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, int dev) {
   switch (tile) {
-    case 0: return launch_dma<2, 5, 4, 1, KIND>(a, grid, lds, s);
-    case 1: return launch_dma<2, 5, 2, 2, KIND>(a, grid, lds, s);
-    default: return launch_dma<1, 5, 4, 1, KIND>(a, grid, lds, s);
+    case 0: return launch_dma<2, 5, 4, 1, KIND>(a, grid, lds, s, dev);
+    case 1: return launch_dma<2, 5, 2, 2, KIND>(a, grid, lds, s, dev);
+    default: return launch_dma<1, 5, 4, 1, KIND>(a, grid, lds, s, dev);
   }
 }
 
@@ -811,28 +805,25 @@ static const TileCfg kTiles[] = {
 static const int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int CK, int KIND>
-static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+static int launch_inst(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, int dev) {
   auto kern = conv_mfma_kernel<WM, WN, WAVES_M, WAVES_N, CK, KIND>;
-  static size_t configured = 0;
-  if (lds > configured) {   // raise the dynamic-LDS limit once per instantiation (host-side state only)
-    RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
-  }
+  static size_t configured[RCV_MAX_DEVICES];   // raise the dynamic-LDS limit once per instantiation and device (host-side state only)
+  RCV_ENSURE_LDS(kern, lds, dev, configured);
   hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, a);
   RCV_HIP(hipGetLastError());
   return RCV_OK;
 }
 
 template <int CK, int KIND>
-static int launch_tile(int tile, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+static int launch_tile(int tile, const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, int dev) {
   switch (tile) {
-    case 0: return launch_inst<2, 5, 4, 1, CK, KIND>(a, grid, lds, s);
-    case 1: return launch_inst<2, 5, 2, 2, CK, KIND>(a, grid, lds, s);
-    case 2: return launch_inst<2, 5, 1, 4, CK, KIND>(a, grid, lds, s);
-    case 3: return launch_inst<1, 5, 1, 4, CK, KIND>(a, grid, lds, s);
-    case 4: return launch_inst<1, 5, 4, 1, CK, KIND>(a, grid, lds, s);
-    case 5: return launch_inst<1, 5, 2, 2, CK, KIND>(a, grid, lds, s);
-    default: return launch_inst<1, 5, 1, 2, CK, KIND>(a, grid, lds, s);
+    case 0: return launch_inst<2, 5, 4, 1, CK, KIND>(a, grid, lds, s, dev);
+    case 1: return launch_inst<2, 5, 2, 2, CK, KIND>(a, grid, lds, s, dev);
+    case 2: return launch_inst<2, 5, 1, 4, CK, KIND>(a, grid, lds, s, dev);
+    case 3: return launch_inst<1, 5, 1, 4, CK, KIND>(a, grid, lds, s, dev);
+    case 4: return launch_inst<1, 5, 4, 1, CK, KIND>(a, grid, lds, s, dev);
+    case 5: return launch_inst<1, 5, 2, 2, CK, KIND>(a, grid, lds, s, dev);
+    default: return launch_inst<1, 5, 1, 2, CK, KIND>(a, grid, lds, s, dev);
   }
 }
 
@@ -893,7 +884,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   // candidates by (virtual) output-channel count; minimise padded work, prefer the larger tile on ties
   // LDS-DMA filter streaming pays where the filter dominates the staged bytes (wide layers); with few input
   // channels its 4-channel chunks fragment the HBM-bound input reads instead
-  const bool use_dma = mode != RCV_LOAD_NCHW && Cin >= 64 && CinP % 8 == 0 && (long long)N * H * W * Cin < (1ll << 31) && !getenv("RCV_NO_DMA");
+  const bool use_dma = mode != RCV_LOAD_NCHW && Cin >= 64 && CinP % 8 == 0 && (long long)N * H * W * Cin < (1ll << 31) && !RCV_ENV("RCV_NO_DMA");
   (void)Q;
   long best = -1;
   pl->tile = -1;
@@ -903,7 +894,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
     if (pl->kind == KIND_TMERGED && cot < pl->CoutP) continue;   // merged layout: all parities in one workgroup
     if (pl->CoutP >= 128 && cot < 64) continue;
     if (pl->CoutP >= 64 && cot < 32) continue;
-    const bool tall5 = use_dma && t == 5 && pl->kind == KIND_TPHASE && !getenv("RCV_NO_TALL");     // 32-channel tile: only as KIND_TALL
+    const bool tall5 = use_dma && t == 5 && pl->kind == KIND_TPHASE && !RCV_ENV("RCV_NO_TALL");     // 32-channel tile: only as KIND_TALL
     const bool dma_tile = (use_dma && (t == 0 || t == 1 || t == 4)) || tall5;
     const int cap = dma_tile ? kTiles[t].nt() * 2 : 65535;      // DMA variant: the input chunk (>= 8 channels = 2 quads per pixel) rides in 4 register slots per thread
     int R, Wt, tx, ty;
@@ -914,7 +905,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
     }
   }
   RCV_CHECK_ARG(pl->tile >= 0, "conv: no tile configuration for Cout=%d", Cout);
-  if (pl->kind == KIND_TPHASE && use_dma && pl->tile == 2 && !getenv("RCV_NO_TALL")) {
+  if (pl->kind == KIND_TPHASE && use_dma && pl->tile == 2 && !RCV_ENV("RCV_NO_TALL")) {
     // 32-channel transposed conv with >= 64 input channels: the half-size tile runs as KIND_TALL on the LDS-DMA kernel
     // (64 -> 32 at 32x60x80: 0.100 instead of 0.140 ms)
     int R, Wt, tx, ty;
@@ -934,7 +925,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
       }
     }
   }
-  if (const char* ev = getenv("RCV_CONV_TILE")) {      // experiment override: "tile,R,Wt"
+  if (const char* ev = RCV_ENV("RCV_CONV_TILE")) {      // experiment override: "tile,R,Wt"
     int t = -1, r = 0, wt = 0;
     if (sscanf(ev, "%d,%d,%d", &t, &r, &wt) == 3 && t >= 0 && t < kNumTiles && r > 0 && wt > 0 && r * wt <= kTiles[t].pix() &&
         kTiles[t].cot() <= round_up(pl->CoutP, 16) + 0) {
@@ -944,13 +935,13 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   const TileCfg& tc = kTiles[pl->tile];
   tile_halo(pl->kind, pl->R, pl->Wt, s, d, &pl->IH, &pl->IW);
   const int ntaps = pl->kind == KIND_GATHER ? 9 : 4;
-  const bool tall5 = pl->tile == 5 && pl->kind == KIND_TPHASE && !getenv("RCV_NO_TALL");
+  const bool tall5 = pl->tile == 5 && pl->kind == KIND_TPHASE && !RCV_ENV("RCV_NO_TALL");
   pl->dma = use_dma && (pl->tile == 0 || pl->tile == 1 || pl->tile == 4 || tall5) && pl->IH * pl->IW <= tc.nt() * 2;
   pl->xk = 0;
   size_t floats;
   if (pl->dma) {
     pl->CK = 4;
-    const int taps_dma = (pl->kind == KIND_TPHASE && (pl->tile == 4 || pl->tile == 5) && !getenv("RCV_NO_TALL")) ? 9 : ntaps;   // KIND_TALL below
+    const int taps_dma = (pl->kind == KIND_TPHASE && (pl->tile == 4 || pl->tile == 5) && !RCV_ENV("RCV_NO_TALL")) ? 9 : ntaps;   // KIND_TALL below
     pl->wl_floats = ntaps * 4 * tc.cot();
     // input chunk: 16 channels per staging pass when the tile fits the register slots and leaves room for two workgroups per CU
     // (the pipeline overlaps one workgroup's staging with the other's contraction), else 8
@@ -973,7 +964,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   pl->n_phases = pl->kind == KIND_TPHASE ? 4 : 1;
   const int n_pix_tiles = N * pl->tiles_x * pl->tiles_y;
   pl->total_tiles = n_pix_tiles * pl->n_co_tiles * pl->n_phases;
-  if (pl->kind == KIND_TPHASE && pl->dma && (pl->tile == 4 || pl->tile == 5) && !getenv("RCV_NO_TALL")) {
+  if (pl->kind == KIND_TPHASE && pl->dma && (pl->tile == 4 || pl->tile == 5) && !RCV_ENV("RCV_NO_TALL")) {
     // all four output parities in one workgroup (KIND_TALL): one staging of the input and nine taps per chunk instead of four
     // workgroups with 1/2/2/4 taps each paying the whole per-chunk overhead; n_phases stays 4: the statistics rows are per parity
     pl->kind = KIND_TALL;
@@ -988,8 +979,13 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
 
 int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query) {
   ConvPlan pl;
-  int rc = make_plan(h, op, &pl);
-  if (rc) return rc;
+  if (!rcv_plan_get(h, op, &pl)) {
+    memset(&pl, 0, sizeof(pl));
+    const int rc = make_plan(h, op, &pl);
+    if (rc) return rc;
+    pl.dev = h->device;
+    rcv_plan_put(h, op, pl);
+  }
   const int Cout = op->i[RCV_I_COUT];
   const int n_pix_tiles = op->i[RCV_I_N] * pl.tiles_x * pl.tiles_y;
   const int n_part = (pl.narrow || pl.first) ? pl.grid : n_pix_tiles * pl.n_phases;
@@ -1049,14 +1045,14 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   const dim3 grid(pl.grid);
   if (pl.dma) {
     if (pl.kind == KIND_TALL)
-      return pl.tile == 4 ? launch_dma<1, 5, 4, 1, KIND_TALL>(a, grid, pl.lds, s) : launch_dma<1, 5, 2, 2, KIND_TALL>(a, grid, pl.lds, s);
-    if (pl.kind == KIND_TPHASE) return launch_dma_tile<KIND_TPHASE>(pl.tile, a, grid, pl.lds, s);
-    if (pl.kind == KIND_TMERGED) return launch_dma_tile<KIND_TMERGED>(pl.tile, a, grid, pl.lds, s);
-    return launch_dma_tile<KIND_GATHER>(pl.tile, a, grid, pl.lds, s);
+      return pl.tile == 4 ? launch_dma<1, 5, 4, 1, KIND_TALL>(a, grid, pl.lds, s, h->device) : launch_dma<1, 5, 2, 2, KIND_TALL>(a, grid, pl.lds, s, h->device);
+    if (pl.kind == KIND_TPHASE) return launch_dma_tile<KIND_TPHASE>(pl.tile, a, grid, pl.lds, s, h->device);
+    if (pl.kind == KIND_TMERGED) return launch_dma_tile<KIND_TMERGED>(pl.tile, a, grid, pl.lds, s, h->device);
+    return launch_dma_tile<KIND_GATHER>(pl.tile, a, grid, pl.lds, s, h->device);
   }
   if (pl.kind == KIND_TPHASE)
-    return pl.CK == 8 ? launch_tile<8, KIND_TPHASE>(pl.tile, a, grid, pl.lds, s) : launch_tile<4, KIND_TPHASE>(pl.tile, a, grid, pl.lds, s);
+    return pl.CK == 8 ? launch_tile<8, KIND_TPHASE>(pl.tile, a, grid, pl.lds, s, h->device) : launch_tile<4, KIND_TPHASE>(pl.tile, a, grid, pl.lds, s, h->device);
   if (pl.kind == KIND_TMERGED)
-    return pl.CK == 8 ? launch_tile<8, KIND_TMERGED>(pl.tile, a, grid, pl.lds, s) : launch_tile<4, KIND_TMERGED>(pl.tile, a, grid, pl.lds, s);
-  return pl.CK == 8 ? launch_tile<8, KIND_GATHER>(pl.tile, a, grid, pl.lds, s) : launch_tile<4, KIND_GATHER>(pl.tile, a, grid, pl.lds, s);
+    return pl.CK == 8 ? launch_tile<8, KIND_TMERGED>(pl.tile, a, grid, pl.lds, s, h->device) : launch_tile<4, KIND_TMERGED>(pl.tile, a, grid, pl.lds, s, h->device);
+  return pl.CK == 8 ? launch_tile<8, KIND_GATHER>(pl.tile, a, grid, pl.lds, s, h->device) : launch_tile<4, KIND_GATHER>(pl.tile, a, grid, pl.lds, s, h->device);
 }

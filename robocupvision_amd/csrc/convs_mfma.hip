@@ -319,10 +319,10 @@ static inline bool narrow_wn_built(int WN, int CK, int WM) {
 
 bool convs_supported(const rcv_handle* h, const rcv_op* op, int kind, int CinP, int CoutV) {
   (void)h; (void)op;
-  if (getenv("RCV_NO_NARROW")) return false;
+  if (RCV_ENV("RCV_NO_NARROW")) return false;
   if (kind == KIND_TPHASE) return false;
   if (!(CinP == 4 || CinP == 8 || CinP == 16 || CinP == 32)) return false;
-  if (kind == KIND_TMERGED && (CinP == 16 || CinP == 32) && round_up(CoutV, 16) == 64 && !getenv("RCV_NO_NARROW4")) return true;   // 4 x 16 virtual channels
+  if (kind == KIND_TMERGED && (CinP == 16 || CinP == 32) && round_up(CoutV, 16) == 64 && !RCV_ENV("RCV_NO_NARROW4")) return true;   // 4 x 16 virtual channels
   return round_up(CoutV, 16) <= 32;
 }
 
@@ -345,7 +345,7 @@ int convs_make_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* p
   // (every slot costs, used or not), staging the halo, a fixed part (barriers, prefetch issue, epilogue address work).
   double best = -1.0;
   int ovR = 0, ovW = 0, ovWN = 0;
-  if (const char* ev = getenv("RCV_CONVS_TILE")) sscanf(ev, "%d,%d,%d", &ovR, &ovW, &ovWN);
+  if (const char* ev = RCV_ENV("RCV_CONVS_TILE")) sscanf(ev, "%d,%d,%d", &ovR, &ovW, &ovWN);
   for (int WN : kNarrowWNs) {
     if (!narrow_wn_built(WN, CinP, pl->WM) || (ovWN > 0 && WN != ovWN)) continue;
     const int PIX = 64 * WN;
@@ -383,7 +383,7 @@ int convs_make_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* p
   int occ = (int)((size_t)h->max_lds / pl->lds);
   if (occ > 2) occ = 2;                       // launch bounds: 2 waves per SIMD
   if (occ < 1) occ = 1;
-  if (const char* ev = getenv("RCV_CONVS_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4) occ = o; }
+  if (const char* ev = RCV_ENV("RCV_CONVS_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4) occ = o; }
   const int resident = h->num_cus * occ;
   const int per = ceil_div(pl->total_tiles, resident);
   pl->grid = ceil_div(pl->total_tiles, per);
@@ -393,11 +393,8 @@ int convs_make_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* p
 template <int WM, int WN, int CK, int KIND, bool TWO>
 static int convs_launch_inst(const ConvPlan& pl, const ConvArgs& a, hipStream_t s) {
   auto kern = convs_mfma_kernel<WM, WN, CK, KIND, kNarrowXMAX, TWO>;
-  static size_t configured = 0;
-  if (pl.lds > configured) {
-    RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds));
-    configured = pl.lds;
-  }
+  static size_t configured[RCV_MAX_DEVICES];
+  RCV_ENSURE_LDS(kern, pl.lds, pl.dev, configured);
   hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(256), pl.lds, s, a);
   RCV_HIP(hipGetLastError());
   return RCV_OK;

@@ -257,7 +257,7 @@ __global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restr
       float vt = 0.f;
 #pragma unroll
       for (int c = 0; c < CLS_MAX_OUT; ++c) if (c == tg) vt = lg[c];
-      const float wt = cw ? cw[tg] : 1.f;
+      const float wt = (unsigned)tg < (unsigned)COUT ? (cw ? cw[tg] : 1.f) : 0.f;   // label outside [0, C) (e.g. -100): ignored, like NLLLoss's ignore_index
       const float nll = (mx - vt) + logf(se);
       a_nll += (double)(wt * nll);
       a_w += (double)wt;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void cls_bwd_kernel(const float* __restrict
 #pragma unroll
       for (int c = 0; c < COUT; ++c) { g[c] = expf(g[c] - mx); se += g[c]; }
       const int tg = (int)target[p];
-      const float kf = (grad_out[0] / loss_out[1]) * (cw ? cw[tg] : 1.f);
+      const float kf = (grad_out[0] / loss_out[1]) * ((unsigned)tg < (unsigned)COUT ? (cw ? cw[tg] : 1.f) : 0.f);
       const float inv = 1.f / se;
 #pragma unroll
       for (int c = 0; c < COUT; ++c) g[c] = __fmul_rn(kf, fmaf(g[c], inv, c == tg ? -1.f : 0.f));      // explicit: same rounding as ce_bwd_kernel
@@ -436,7 +436,7 @@ __global__ void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* _
     float vt = 0.f;
 #pragma unroll
     for (int c = 0; c < CE_MAX_C; ++c) if (c == tg) vt = v[c];
-    const float w = cw ? cw[tg] : 1.f;
+    const float w = (unsigned)tg < (unsigned)C ? (cw ? cw[tg] : 1.f) : 0.f;   // label outside [0, C) (e.g. -100): ignored, like NLLLoss's ignore_index
     const float nll = (mx - vt) + logf(se);
     a_nll += (double)(w * nll);
     a_w += (double)w;
@@ -488,7 +488,7 @@ __global__ void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* _
 #pragma unroll
     for (int c = 0; c < CE_MAX_C; ++c) if (c < C) { v[c] = expf(v[c] - mx); se += v[c]; }
     const int tg = (int)target[p];
-    const float k = scale * (cw ? cw[tg] : 1.f);
+    const float k = scale * ((unsigned)tg < (unsigned)C ? (cw ? cw[tg] : 1.f) : 0.f);
     const float inv = 1.f / se;
 #pragma unroll
     for (int c = 0; c < CE_MAX_C; ++c)
@@ -754,18 +754,21 @@ template <bool MET>
 __global__ void adam_l1_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                const float* __restrict__ lr_elem, size_t n, float lr, float b1, float b2, float eps, float decay,
                                float grad_scale, float bc1, float bc2_sqrt, double* part, const float* __restrict__ loss_stats,
-                               double* metrics) {
+                               double* metrics, const uint8_t* __restrict__ prune) {
   float asum = 0.f;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
     const float pv = p[e];
-    if (MET) asum += fabsf(pv);
+    if (MET) asum += fabsf(pv);                       // l1reg(model) runs over every parameter, stepped or not
+    const float lre = lr_elem ? lr_elem[e] : lr;
+    if (lre == 0.f) continue;                         // parameter without a gradient (outside the graph / the groups): untouched, as under torch.optim.Adam
     const float sg = pv > 0.f ? 1.f : (pv < 0.f ? -1.f : 0.f);
-    const float gr = fmaf(decay, sg, g[e] * grad_scale);
+    float gr = fmaf(decay, sg, g[e] * grad_scale);
+    if (prune && prune[e]) gr = 0.f;                  // train.py:59-65: param.grad[indices] = 0 after backward (the L1 part included)
     const float mm = b1 * m[e] + (1.f - b1) * gr;
     const float vv = b2 * v[e] + (1.f - b2) * gr * gr;
     m[e] = mm; v[e] = vv;
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    const float step = (lr_elem ? lr_elem[e] : lr) / bc1;
+    const float step = lre / bc1;
     p[e] = pv - step * (mm / denom);
   }
   if (MET) {
@@ -1150,11 +1153,13 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
         RCV_CHECK_ARG(part && op->p[RCV_P_X4] && op->i[RCV_I_NPART] == g, "adam + metrics: needs loss stats and a %d-row workspace (rcv_op_workspace)", g);
         hipLaunchKernelGGL(adam_l1_kernel<true>, dim3(g), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
                            (float*)op->p[RCV_P_X0], (float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], n, op->f[0], b1, b2, op->f[3],
-                           op->f[4], op->f[5], bc1, bc2s, part, (const float*)op->p[RCV_P_X4], (double*)op->p[RCV_P_X3]);
+                           op->f[4], op->f[5], bc1, bc2s, part, (const float*)op->p[RCV_P_X4], (double*)op->p[RCV_P_X3],
+                           (const uint8_t*)op->p[RCV_P_X5]);
       } else {
         hipLaunchKernelGGL(adam_l1_kernel<false>, dim3(g), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
                            (float*)op->p[RCV_P_X0], (float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], n, op->f[0], b1, b2, op->f[3],
-                           op->f[4], op->f[5], bc1, bc2s, (double*)nullptr, (const float*)nullptr, (double*)nullptr);
+                           op->f[4], op->f[5], bc1, bc2s, (double*)nullptr, (const float*)nullptr, (double*)nullptr,
+                           (const uint8_t*)op->p[RCV_P_X5]);
       }
       break;
     }

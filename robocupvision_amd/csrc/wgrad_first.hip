@@ -151,7 +151,7 @@ __global__ __launch_bounds__(384) void wgrad_first_kernel(const WgradArgs a, int
 // host side
 // --------------------------------------------------------------------------------------------
 bool wgrad_first_supported(const rcv_op* op) {
-  if (getenv("RCV_NO_WGRAD_FIRST")) return false;
+  if (RCV_ENV("RCV_NO_WGRAD_FIRST")) return false;
   const int d = op->i[RCV_I_DIL];
   return op->i[RCV_I_INMODE] == RCV_LOAD_NCHW && op->i[RCV_I_CIN] <= 3 && op->i[RCV_I_COUT] == 8 && op->i[RCV_I_STRIDE] == 1 &&
          (d == 1 || d == 2) && op->i[RCV_I_INMODE2] != RCV_LOAD_NCHW;

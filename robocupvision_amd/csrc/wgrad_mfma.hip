@@ -430,26 +430,19 @@ static const WTile kWT[] = {
     {1, 1, 1, 1, 4, 2, 0},  // 7: 16 x (9 taps x <=3 ch folded into 2 blocks)
     {1, 1, 1, 1, 4, 5, 0},  // 8: 16 x (9 taps x <=8 ch folded into 5 blocks)
 };
-static const int kNumWT = sizeof(kWT) / sizeof(kWT[0]);
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, bool SPEC>
-static int wlaunch_inst(const WgradArgs& a, bool gtwo, dim3 grid, size_t lds, hipStream_t s) {
+static int wlaunch_inst(const WgradArgs& a, bool gtwo, dim3 grid, size_t lds, hipStream_t s, int dev) {
   constexpr int NT = WAVES_M * WAVES_N * WAVES_K * 64 + (SPEC ? 256 : 0);     // consumer (+ producer) waves
   if (gtwo) {
     auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, SPEC, true>;
-    static size_t configured = 0;
-    if (lds > configured) {
-      RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = lds;
-    }
+    static size_t configured[RCV_MAX_DEVICES];
+    RCV_ENSURE_LDS(kern, lds, dev, configured);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, a);
   } else {
     auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, SPEC, false>;
-    static size_t configured = 0;
-    if (lds > configured) {
-      RCV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured = lds;
-    }
+    static size_t configured[RCV_MAX_DEVICES];
+    RCV_ENSURE_LDS(kern, lds, dev, configured);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, a);
   }
   RCV_HIP(hipGetLastError());
@@ -483,7 +476,7 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
     pl->IH = 8 + 2 * d; pl->IW = 64 + 2 * d; pl->SP = 8; pl->SG = 1; pl->pl_floats = 0; pl->gl_floats = 0;
     return RCV_OK;
   }
-  const bool fold = CA <= 8 && cbt_want == 16 && !getenv("RCV_NO_FOLD");
+  const bool fold = CA <= 8 && cbt_want == 16 && !RCV_ENV("RCV_NO_FOLD");
   if (fold) pl->tile = 9 * CA <= 32 ? 7 : 8;
   else {
     for (int t = 0; t < 7; ++t) if (kWT[t].cbt() == cbt_want && kWT[t].cat() == cat_want) pl->tile = t;
@@ -500,7 +493,7 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   else pl->SG = s == 1 ? (wt.cat() % 32 == 0 ? wt.cat() + 16 : wt.cat()) : wt.cat() + 8;
   // pixel tile: widest row segment, then as many rows as the prefetch registers and the LDS budget allow
   int per_cu = wt.SPEC ? 1 : 2;                     // SPEC: 512 threads, two LDS buffers => one workgroup per CU
-  if (const char* ev = getenv("RCV_WGRAD_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4 && !wt.SPEC) per_cu = o; }
+  if (const char* ev = RCV_ENV("RCV_WGRAD_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4 && !wt.SPEC) per_cu = o; }
   const size_t budget = (wt.SPEC ? 78 : 160 / per_cu) * 1024 / sizeof(float);   // SPEC: per buffer
   // Pixel tile: among the (row segment, rows) shapes that fit the LDS budget, the one that stages the fewest global bytes per
   // pointwise pixel (the gathered tile carries a halo of 2*dil rows and columns: a 1 x 80 tile of a stride-1 layer reads its gathered
@@ -510,7 +503,7 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
     const int m1 = op->i[RCV_I_INMODE], m2 = op->i[RCV_I_INMODE2];
     const double cG = (double)CA * ((m1 == RCV_LOAD_GRAD_ENC || m1 == RCV_LOAD_GRAD_DEC) ? 2 : 1);
     const double cP = (double)CB * ((m2 == RCV_LOAD_GRAD_ENC || m2 == RCV_LOAD_GRAD_DEC) ? 2 : 1);
-    const bool wide_first = getenv("RCV_WGRAD_WIDE") != nullptr;
+    const bool wide_first = RCV_ENV("RCV_WGRAD_WIDE") != nullptr;
     const int max_px = wt.SPEC ? 1024 : 640;
     double best_cost = 1e30;
     int prevWt = 0;
@@ -566,7 +559,7 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   pl->nsplit = nsplit;
   pl->grid = dim3(nsplit * ctiles, 1, 1);
   pl->nctiles = ctiles;
-  if (getenv("RCV_DEBUG_PLAN"))
+  if (RCV_ENV("RCV_DEBUG_PLAN"))
     fprintf(stderr, "wgrad plan: tile %d  R=%d Wt=%d (%d px) IHxIW=%dx%d  ntiles=%d nsplit=%d ctiles=%d lds=%zu\n", pl->tile, pl->R, pl->Wt,
             pl->R * pl->Wt4, pl->IH, pl->IW, ntiles, nsplit, ctiles, pl->lds);
   return RCV_OK;
@@ -588,8 +581,12 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     return RCV_OK;
   }
   WPlan pl;
-  int rc = wmake_plan(h, op, &pl);
-  if (rc) return rc;
+  if (!rcv_plan_get(h, op, &pl)) {
+    memset(&pl, 0, sizeof(pl));
+    const int rc = wmake_plan(h, op, &pl);
+    if (rc) return rc;
+    rcv_plan_put(h, op, pl);
+  }
   if (query && pl.first) {
     snprintf(query->label, sizeof(query->label), "wgrad_first<%d>", op->i[RCV_I_DIL]);
     query->n_part = 0;
@@ -630,14 +627,14 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   a.part_bias = (op->flags & RCV_F_BIAS) ? a.part + (size_t)pl.nsplit * 9 * pl.CBP * pl.CAP : nullptr;
   if (pl.first) return wgrad_first_launch(h, a, s);
   switch (pl.tile) {
-    case 0: return wlaunch_inst<2, 2, 2, 2, 1, 0, true>(a, g_two, pl.grid, pl.lds, s);
-    case 1: return wlaunch_inst<2, 2, 2, 1, 2, 0, true>(a, g_two, pl.grid, pl.lds, s);
-    case 2: return wlaunch_inst<2, 2, 1, 2, 2, 0, true>(a, g_two, pl.grid, pl.lds, s);
-    case 3: return wlaunch_inst<2, 2, 1, 1, 4, 0, true>(a, g_two, pl.grid, pl.lds, s);
-    case 4: return wlaunch_inst<2, 1, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s);
-    case 5: return wlaunch_inst<1, 2, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s);
-    case 6: return wlaunch_inst<1, 1, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s);
-    case 7: return wlaunch_inst<1, 1, 1, 1, 4, 2, false>(a, g_two, pl.grid, pl.lds, s);
-    default: return wlaunch_inst<1, 1, 1, 1, 4, 5, false>(a, g_two, pl.grid, pl.lds, s);
+    case 0: return wlaunch_inst<2, 2, 2, 2, 1, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 1: return wlaunch_inst<2, 2, 2, 1, 2, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 2: return wlaunch_inst<2, 2, 1, 2, 2, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 3: return wlaunch_inst<2, 2, 1, 1, 4, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 4: return wlaunch_inst<2, 1, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 5: return wlaunch_inst<1, 2, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 6: return wlaunch_inst<1, 1, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 7: return wlaunch_inst<1, 1, 1, 1, 4, 2, false>(a, g_two, pl.grid, pl.lds, s, h->device);
+    default: return wlaunch_inst<1, 1, 1, 1, 4, 5, false>(a, g_two, pl.grid, pl.lds, s, h->device);
   }
 }

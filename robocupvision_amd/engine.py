@@ -17,6 +17,7 @@ Data layout in HBM:
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 from typing import Dict, List, Optional, Sequence
@@ -53,6 +54,28 @@ def _conv_order(d: dict) -> str:
     elif order not in ("relu_bn", "bn_relu"):
         raise L.RcvError("conv node order '%s' unknown" % order)
     return order
+
+
+def run_bucketed(marks, numel: int, n_buckets: int, n_ops: int, run_slice, grad_ready, join):
+    """The data-parallel backward schedule: run the op list in slices and report finished gradient ranges.
+
+    ``marks`` = [(ops executed, lowest final flat-gradient offset)] (Plan.bwd_marks); ``run_slice(start, end)`` enqueues
+    ops [start, end) without joining the filter-gradient stream; ``grad_ready(lo, hi)`` is told that flat.grad[lo:hi] is final
+    (descending, contiguous ranges that tile [0, numel)); ``join()`` makes the compute stream wait for the filter-gradient
+    stream once at the end.  Engine._run_backward drives the real kernels through this; tests/test_dp_gloo.py drives a
+    simulated executor through the very same function."""
+    done, hi = 0, numel
+    for (end, lo) in select_buckets(marks, numel, n_buckets):
+        run_slice(done, end)
+        done = end
+        if lo < hi:
+            grad_ready(lo, hi)
+            hi = lo
+    if done < n_ops:
+        run_slice(done, n_ops)
+    if hi > 0:
+        grad_ready(0, hi)
+    join()
 
 
 def select_buckets(marks, numel: int, n_buckets: int):
@@ -154,8 +177,14 @@ class Plan:
         self.bytes = 0
 
 
+PLAN_BYTES_BUDGET = 96 << 30      # cached plans beyond this many bytes of engine buffers are dropped, least recently used first
+
+
 class Engine:
-    def __init__(self, graph: dict, params: Sequence[torch.nn.Parameter], bn_modules: Sequence[torch.nn.Module]):
+    def __init__(self, graph: dict, params: Sequence[torch.nn.Parameter], bn_modules: Sequence[torch.nn.Module], dry_run: bool = False):
+        # dry_run: lower graphs to op lists on whatever device the parameters are on (CPU included) through a planning-only
+        # library handle; nothing can be executed.  Used by the CPU tests of the data-parallel schedule.
+        self.dry_run = dry_run
         self.graph = graph
         self.param_list = list(params)
         self.bn_modules = list(bn_modules)
@@ -169,7 +198,10 @@ class Engine:
                 used.add(id(d["bn"].bias))
         self.param_used = [id(p) in used for p in self.param_list]
         self.flat: Optional[FlatParams] = None
-        self.plans: Dict[tuple, Plan] = {}
+        self.plans: "collections.OrderedDict[tuple, Plan]" = collections.OrderedDict()
+        self.plan_bytes_budget = PLAN_BYTES_BUDGET
+        self._generation = 0                 # one forward in flight: backward refuses a stale forward
+        self._last = None
         self.device: Optional[torch.device] = None
         self.handle = None
         # data parallel: called as cb(lo, hi) during backward whenever flat.grad[lo:hi] is final (reverse layer order)
@@ -178,6 +210,13 @@ class Engine:
 
     # ------------------------------------------------------------------ device / parameter state
     def _ensure_device(self, dev: torch.device):
+        if self.dry_run:
+            if self.flat is None or not self.flat.intact() or self.device != dev:
+                self.device = dev
+                self.handle = L.planner_handle(256)
+                self.flat = FlatParams(self.param_list)
+                self.plans.clear()
+            return
         if dev.type != "cuda":
             raise L.RcvError("robocupvision_amd computes on an MI355X (HIP) device only; got a tensor on '%s'. "
                              "There is no CPU path: move the model and inputs to cuda." % dev)
@@ -654,14 +693,15 @@ class Engine:
         plan.bwd_marks = marks if training else []
 
         # ---- the pack launch goes first in the forward list ----
-        table = (L.RcvPackJob * len(jobs))(*jobs)
-        nbytes = C.sizeof(table)
-        host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
-        dev_table = host.to(self.device)
-        plan.keep.append(dev_table)
-        max_elems = max((4 if j.merged else 9) * j.rows_pad * j.cols_pad for j in jobs)
-        pack_op = L.make_op(L.OP_PACK, 0, count=len(jobs), aux0=max_elems, p_in=dev_table.data_ptr())
-        head = [pack_op] + pre
+        head = list(pre)
+        if jobs:        # (a graph without 3x3 filters -- a lone 1x1 classifier -- packs nothing)
+            table = (L.RcvPackJob * len(jobs))(*jobs)
+            host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
+            dev_table = host.to(self.device)
+            plan.keep.append(dev_table)
+            assert C.sizeof(table) == dev_table.numel()
+            max_elems = max((4 if j.merged else 9) * j.rows_pad * j.cols_pad for j in jobs)
+            head = [L.make_op(L.OP_PACK, 0, count=len(jobs), aux0=max_elems, p_in=dev_table.data_ptr())] + head
         for slots in plan.input_slots:
             for i, (is_bwd, k, sl) in enumerate(slots):
                 if not is_bwd:
@@ -675,7 +715,6 @@ class Engine:
                     op.flags |= L.F_SIDE_STREAM
         plan.fwd = L.OpList(fwd)
         plan.bwd = L.OpList(bwd)
-        assert nbytes == dev_table.numel()
         return plan
 
     # ------------------------------------------------------------------ execution
@@ -686,6 +725,19 @@ class Engine:
         if plan is None:
             plan = self._build([tuple(t.shape) for t in inputs], training)
             self.plans[key] = plan
+            # every distinct (shape, mode) owns its activations (4.9 GB at 32x640x480): drop the least recently used ones beyond
+            # the budget (never the plan just built, nor the one an un-finished forward/backward pair is using)
+            total = sum(pl.bytes for pl in self.plans.values())
+            for k in list(self.plans):
+                if total <= self.plan_bytes_budget:
+                    break
+                pl = self.plans[k]
+                if pl is plan or (self._last is not None and pl is self._last[0]):
+                    continue
+                total -= pl.bytes
+                del self.plans[k]
+        else:
+            self.plans.move_to_end(key)
         return plan
 
     def forward(self, inputs: Sequence[torch.Tensor], training: bool) -> torch.Tensor:
@@ -702,6 +754,7 @@ class Engine:
             if nbt:
                 torch._foreach_add_(nbt, 1)
         self._last = (plan, [t for t in inputs])
+        self._generation += 1
         return plan.logits
 
     def profile_last(self, reps: int = 3):
@@ -744,7 +797,14 @@ class Engine:
                              "shape": "%dx%dx%d %d->%d s%d" % (n, h, w, cin, cout, i[L.RCV_I_STRIDE]), "bwd": lst is not plan.fwd})
         return rows
 
-    def backward(self, dlogits: torch.Tensor):
+    def backward(self, dlogits: torch.Tensor, generation: Optional[int] = None):
+        """Backward of the LAST forward.  The activations, the logits and the op lists are engine-owned and overwritten by the next
+        forward of this model (any shape, train or eval), so only one forward may be in flight: ``generation`` (the value of
+        ``_generation`` right after the forward being differentiated) is checked against the current one."""
+        if generation is not None and generation != self._generation:
+            raise L.RcvError("backward of a stale forward: this model ran another forward (generation %d -> %d) before "
+                             "loss.backward(); the engine keeps ONE forward in flight (its activations are overwritten by the "
+                             "next call) -- call backward before the next forward, or clone what you need" % (generation, self._generation))
         plan, _inputs = self._last
         if plan.bwd is None or plan.bwd.n == 0:
             raise L.RcvError("backward called on an eval-mode forward; call model.train() first")
@@ -787,28 +847,24 @@ class Engine:
             if lst is not None:
                 self._set_side(lst, plan.side_on)
 
-    def _run_backward(self, plan: Plan, ops: L.OpList):
-        if not plan.side_decided:
-            self._decide_side_stream(plan, ops)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
+    def _run_backward(self, plan: Plan, ops):
+        if self.dry_run:
+            plan.side_decided = True
+            stream = 0
+        else:
+            if not plan.side_decided:
+                self._decide_side_stream(plan, ops)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
         if self.grad_ready_cb is None or not plan.bwd_marks:
             ops.run(self.handle, stream)
             return
         # bucketed: run the op list in slices and hand finished gradient ranges to the caller (all-reduce on a side stream).  The
         # slices do not join the filter-gradient stream back (that would stall the d(activation) chain at every bucket border): the
         # callback makes ITS stream wait for it (join_side), the compute stream joins once at the end.
-        done, hi = 0, self.flat.numel
-        for (end, lo) in select_buckets(plan.bwd_marks, self.flat.numel, self.grad_buckets):
-            ops.run_slice(self.handle, stream, done, end, join=False)
-            done = end
-            if lo < hi:
-                self.grad_ready_cb(lo, hi)
-                hi = lo
-        if done < ops.n:
-            ops.run_slice(self.handle, stream, done, ops.n, join=False)
-        if hi > 0:
-            self.grad_ready_cb(0, hi)
-        L.join_side(self.handle, stream)
+        run_bucketed(plan.bwd_marks, self.flat.numel, self.grad_buckets, ops.n,
+                     lambda a, b: ops.run_slice(self.handle, stream, a, b, join=False),
+                     self.grad_ready_cb,
+                     (lambda: None) if self.dry_run else (lambda: L.join_side(self.handle, stream)))
 
     # ------------------------------------------------------------------ loss fused into the classifier (Trainer fast path)
     def _ce_variant(self, plan: Plan):
@@ -868,6 +924,7 @@ class Engine:
         if nbt:
             torch._foreach_add_(nbt, 1)
         self._last = (plan, [t for t in inputs])
+        self._generation += 1
         self._last_ce = (targets, weight)        # keep alive until backward_ce
         return plan.logits, ce["loss_out"], ce["argmax"]
 

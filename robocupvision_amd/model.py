@@ -34,6 +34,7 @@ class _EngineFunction(torch.autograd.Function):
         inputs = [t.detach() for t in tensors[:n_inputs]]
         out = engine.forward(inputs, training)
         ctx.engine = engine
+        ctx.generation = engine._generation
         ctx.n_inputs = n_inputs
         ctx.n_params = len(tensors) - n_inputs
         return out
@@ -48,7 +49,7 @@ class _EngineFunction(torch.autograd.Function):
         for p in fl.params:
             if p.grad is not None and base <= p.grad.data_ptr() < end:
                 p.grad = p.grad.clone()
-        plan = eng.backward(grad_out)
+        plan = eng.backward(grad_out, ctx.generation)
         in_grads = []
         for k in range(ctx.n_inputs):
             g = plan.input_grads[k] if ctx.needs_input_grad[3 + k] else None

@@ -40,7 +40,17 @@ class AdamL1(torch.optim.Optimizer):
         self._lr_elem = None
         self._lr_key = None
         self._met_ws: Optional[torch.Tensor] = None
+        self._prune_src = None            # list of boolean masks (parameters with dim() > 1, parameters() order) or None
+        self._prune_flat: Optional[torch.Tensor] = None
         super().__init__(reference_param_groups(model, lr, transfer), dict(lr=lr, betas=betas, eps=eps))
+
+    def set_prune_mask(self, masks):
+        """train.py:50-65 inside the fused step: ``masks`` = pruneModelNew(model.parameters()) (True = pruned weight).  As in
+        the reference, a pruning run has NO L1 term (train.py:52-55: ``if indices is None: loss += decay*l1reg``): the launch
+        uses decay 0, and zeroes the gradient of the masked elements before the moment update -- what
+        ``param.grad[indices] = 0`` after ``loss.backward()`` leaves for torch.optim.Adam.  None switches it off."""
+        self._prune_src = None if masks is None else list(masks)
+        self._prune_flat = None
 
     def _flat(self):
         eng = self.model._get_engine()
@@ -64,22 +74,41 @@ class AdamL1(torch.optim.Optimizer):
                     view.copy_(p.grad)
         lrs = [(g["lr"], g["params"]) for g in self.param_groups if len(g["params"])]
         uniform = all(abs(lr - lrs[0][0]) == 0.0 for lr, _ in lrs)
+        # a flat parameter outside the five groups, or one the graph never reads (grad None under the reference's autograd: the
+        # pooled head of PB_FCN_2), must not be stepped at all: torch.optim.Adam skips it.  Per-element lr 0 = skip.
+        grouped = set()
+        for _, params in lrs:
+            grouped.update(id(p) for p in params)
+        stepped = [id(p) in grouped and eng.param_used[k] for k, p in enumerate(fl.params)]
         lr_elem_ptr = 0
-        if not uniform:
-            key = tuple(lr for lr, _ in lrs)
+        if not uniform or not all(stepped):
+            key = (tuple(lr for lr, _ in lrs), tuple(stepped))
             if key != self._lr_key:
                 t = torch.zeros_like(fl.data)
                 for lr, params in lrs:
                     for p in params:
                         k = fl.index(p)
-                        t[fl.offsets[k]:fl.offsets[k] + p.numel()] = lr
+                        if stepped[k]:
+                            t[fl.offsets[k]:fl.offsets[k] + p.numel()] = lr
                 self._lr_elem, self._lr_key = t, key
             lr_elem_ptr = self._lr_elem.data_ptr()
+        prune_ptr = 0
+        if self._prune_src is not None:
+            if self._prune_flat is None or self._prune_flat.numel() != fl.numel or self._prune_flat.device != fl.data.device:
+                big = [k for k, p in enumerate(fl.params) if p.dim() > 1]
+                if len(big) != len(self._prune_src):
+                    raise L.RcvError("prune mask list has %d entries, the model has %d parameters with dim() > 1" % (len(self._prune_src), len(big)))
+                t = torch.zeros(fl.numel, dtype=torch.uint8, device=fl.data.device)
+                for k, m in zip(big, self._prune_src):
+                    p = fl.params[k]
+                    t[fl.offsets[k]:fl.offsets[k] + p.numel()] = m.to(device=fl.data.device, dtype=torch.uint8).reshape(-1)
+                self._prune_flat = t
+            prune_ptr = self._prune_flat.data_ptr()
         self._t += 1
         b1, b2 = self.defaults["betas"]
         op = L.make_op(L.OP_ADAM_L1, 0, count=fl.numel, aux0=self._t, f0=lrs[0][0], f1=b1, f2=b2, f3=self.defaults["eps"],
-                       f4=self.decay, f5=self.grad_scale, p_in=fl.data.data_ptr(), p_in2=fl.grad.data_ptr(),
-                       p_x0=self._m.data_ptr(), p_x1=self._v.data_ptr(), p_x2=lr_elem_ptr)
+                       f4=(0.0 if self._prune_src is not None else self.decay), f5=self.grad_scale, p_in=fl.data.data_ptr(), p_in2=fl.grad.data_ptr(),
+                       p_x0=self._m.data_ptr(), p_x1=self._v.data_ptr(), p_x2=lr_elem_ptr, p_x5=prune_ptr)
         if metrics is not None:
             if loss_stats is None or metrics.dtype != torch.float64 or metrics.numel() < 4 or loss_stats.dtype != torch.float32 \
                     or loss_stats.numel() < 3 or not metrics.is_cuda or not loss_stats.is_cuda:

@@ -25,10 +25,71 @@ from .model import CrossEntropyLoss2d, DiceLoss
 from .optim import AdamL1
 
 
+class _HipStreams:
+    """The stream operations GradExchange needs, on the real device (tests/test_dp_gloo.py injects a recording stand-in)."""
+
+    def __init__(self, device, overlap: bool):
+        self.device = device
+        self.comm = torch.cuda.Stream(device=device) if overlap else None
+
+    def current(self):
+        return torch.cuda.current_stream(self.device)
+
+    def wait(self, waiter, waited):
+        waiter.wait_stream(waited)
+
+    def ptr(self, stream) -> int:
+        return stream.cuda_stream
+
+    def on(self, stream):
+        return torch.cuda.stream(stream)
+
+
+class GradExchange:
+    """Sums finished ranges of the flat gradient buffer over the ranks while backward is still running.
+
+    ``grad_ready(lo, hi)`` is the engine's callback (engine.run_bucketed): flat.grad[lo:hi] is final on the compute stream,
+    except for the filter gradients still in flight on the library's side stream.  With a communication stream, that stream
+    (not the compute stream) waits for both and runs the all-reduce, so the remaining backward kernels keep going;
+    ``finish()`` makes the compute stream wait for the last all-reduce before the optimizer reads the buffer."""
+
+    def __init__(self, engine, streams, all_reduce, join_side=None):
+        self.engine = engine
+        self.streams = streams
+        self.all_reduce = all_reduce
+        self.join_side = join_side if join_side is not None else L.join_side
+        self.pending = False
+        self.ranges = []                  # (lo, hi) of this backward pass, in the order they were exchanged
+
+    def begin(self):
+        self.pending = False
+        self.ranges = []
+
+    def grad_ready(self, lo: int, hi: int):
+        eng, st = self.engine, self.streams
+        bucket = eng.flat.grad[lo:hi]
+        self.ranges.append((lo, hi))
+        cur = st.current()
+        if st.comm is None:
+            self.join_side(eng.handle, st.ptr(cur))        # filter gradients are produced on the library's side stream
+            self.all_reduce(bucket)
+            return
+        st.wait(st.comm, cur)
+        self.join_side(eng.handle, st.ptr(st.comm))
+        with st.on(st.comm):
+            self.all_reduce(bucket)
+        self.pending = True
+
+    def finish(self):
+        if self.pending:
+            self.streams.wait(self.streams.current(), self.streams.comm)
+            self.pending = False
+
+
 class Trainer:
     def __init__(self, model, class_weights: Optional[Sequence[float]] = (1, 10, 30, 10, 2), lr: float = 1e-3,
                  decay: float = 1e-6, transfer: int = 0, distributed: bool = False, overlap: bool = True,
-                 use_dice: bool = False, optimizer=None, fuse_loss: bool = True):
+                 use_dice: bool = False, optimizer=None, fuse_loss: bool = True, prune_indices=None):
         self.model = model
         dev = next(model.parameters()).device
         if dev.type != "cuda":
@@ -47,47 +108,49 @@ class Trainer:
         self.distributed = distributed
         self.fuse_loss = fuse_loss and not os.environ.get("RCV_NO_FUSED_LOSS")
         self.world = 1
-        self.comm_stream = None
+        self.exchange: Optional[GradExchange] = None
         self.force_collectives = bool(int(os.environ.get("RCV_FORCE_COLLECTIVES", "0")))   # exercise the path at world size 1
+        # train.py:59-65: gradients of pruned weights are zeroed after backward; prune_indices = pruneModelNew(model.parameters())
+        # (one boolean mask per parameter with dim() > 1, in parameters() order)
+        self.prune_indices = None
+        if prune_indices is not None:
+            self.set_prune_indices(prune_indices)
         if distributed:
             import torch.distributed as dist
             if not dist.is_initialized():
                 raise L.RcvError("distributed=True needs torch.distributed.init_process_group('nccl') first")
             self.world = dist.get_world_size()
             self.optimizer.grad_scale = 1.0 / self.world
-            self.comm_stream = torch.cuda.Stream(device=dev) if overlap else None
-            if os.environ.get("RCV_GRAD_BUCKETS"):       # experiment knob: number of gradient buckets (default 3)
+            if os.environ.get("RCV_GRAD_BUCKETS"):       # number of gradient buckets (default 3)
                 model._get_engine().grad_buckets = max(1, int(os.environ["RCV_GRAD_BUCKETS"]))
+            self.exchange = GradExchange(model._get_engine(), _HipStreams(dev, overlap), dist.all_reduce)
             # identical parameters on every rank before the first step
             for p in model.parameters():
                 dist.broadcast(p.data, 0)
 
-    def _grad_ready(self, lo: int, hi: int):
-        """flat.grad[lo:hi] is final (called from inside backward, reverse layer order): sum it over the ranks on the
-        side stream while the remaining backward kernels keep the compute stream busy."""
-        import torch.distributed as dist
-        eng = self.model._get_engine()
-        fl = eng.flat
-        bucket = fl.grad[lo:hi]
-        cur = torch.cuda.current_stream(self.device)
-        if self.comm_stream is None:
-            L.join_side(eng.handle, cur.cuda_stream)        # filter gradients are produced on the library's side stream
-            dist.all_reduce(bucket)
-            return
-        self.comm_stream.wait_stream(cur)
-        L.join_side(eng.handle, self.comm_stream.cuda_stream)
-        with torch.cuda.stream(self.comm_stream):
-            dist.all_reduce(bucket)
-        self._pending = self.comm_stream
+    def set_prune_indices(self, prune_indices):
+        """The list pruneModelNew(model.parameters()) returns (train.py:345-347): masks aligned with the parameters of dim() > 1."""
+        big = [p for p in self.model.parameters() if p.dim() > 1]
+        prune_indices = list(prune_indices)
+        if len(prune_indices) != len(big):
+            raise ValueError("prune_indices has %d masks, the model has %d parameters with dim() > 1" % (len(prune_indices), len(big)))
+        for m, p in zip(prune_indices, big):
+            if tuple(m.shape) != tuple(p.shape):
+                raise ValueError("prune mask %s does not match parameter %s" % (tuple(m.shape), tuple(p.shape)))
+        self.prune_indices = [m.to(device=self.device, dtype=torch.bool) for m in prune_indices]
+        if hasattr(self.optimizer, "set_prune_mask"):
+            self.optimizer.set_prune_mask(self.prune_indices)
 
     def step(self, imgs: torch.Tensor, targets: torch.Tensor) -> torch.Tensor:
         """One train.py:43-74 iteration; returns the logits tensor (engine-owned, valid until the next forward)."""
         model, opt, crit = self.model, self.optimizer, self.criterion
         model.train()
         opt.zero_grad(set_to_none=True)
-        self._pending = None
         eng = model._get_engine()
-        eng.grad_ready_cb = self._grad_ready if (self.distributed and (self.world > 1 or self.force_collectives)) else None
+        exchanging = self.exchange is not None and (self.world > 1 or self.force_collectives)
+        eng.grad_ready_cb = self.exchange.grad_ready if exchanging else None
+        if exchanging:
+            self.exchange.begin()
         fused = None
         if self.fuse_loss and type(crit) is CrossEntropyLoss2d and imgs.dtype == torch.float32 and imgs.is_contiguous():
             # fast path: the loss is evaluated inside the classifier op and its gradient inside the classifier's backward op
@@ -110,8 +173,16 @@ class Trainer:
             pred = model(imgs)
             ce = crit(pred, targets)
             ce.backward()
-        if self._pending is not None:
-            torch.cuda.current_stream(self.device).wait_stream(self._pending)
+        if exchanging:
+            self.exchange.finish()
+        if self.prune_indices is not None and not hasattr(opt, "set_prune_mask"):
+            # stock optimizers: the literal train.py:59-65 loop on the gradient views (they alias the flat buffer)
+            k = 0
+            for p in model.parameters():
+                if p.dim() > 1:
+                    if p.grad is not None:
+                        p.grad[self.prune_indices[k]] = 0
+                    k += 1
         if isinstance(opt, AdamL1):
             # loss + decay*sum|p|, reg, #correct and the step count are booked by the optimizer launch itself (the parameters
             # it reads are the pre-update ones the reference's l1reg(model) sees): no per-step torch reductions

@@ -67,12 +67,81 @@ def _run_block(layer_kats, name, mod, check_gx=True):
     close(ye, _t(layer_kats[name + "/y_eval"]), name + " y_eval")
 
 
+def _graph_engine(graph, mod):
+    from robocupvision_amd.engine import Engine
+    return Engine(graph, list(mod.parameters()), [m for m in mod.modules() if isinstance(m, torch.nn.BatchNorm2d)])
+
+
 @pytest.mark.parametrize("name,cin,cout,stride", CONV_CASES)
 def test_conv_block(layer_kats, name, cin, cout, stride):
-    if cin % 4:
-        pytest.skip("3-channel input is the NCHW image path, covered by the whole-net tests")
     mod = _load_block(layer_kats, name, M.Conv(cin, cout, 3, stride))
-    _run_block(layer_kats, name, mod)
+    if cin % 4 == 0:
+        _run_block(layer_kats, name, mod)
+        return
+    # The 3-channel block is the network's first layer: it reads the NCHW image directly (conv_first.hip / wgrad_first.hip).
+    # One-node graph with an NCHW input: forward (train, eval), filter / bias / BatchNorm gradients and running statistics against
+    # the reference's values (the image has no gradient in the network, so there is no gx to compare).
+    eng = _graph_engine({"inputs": [{"layout": "nchw"}], "nodes": [mod._node(("in", 0)), {"op": "mat", "src": ("node", 0)}]}, mod)
+    x = _t(layer_kats[name + "/x"]).to(DEV)
+    mod.train()
+    y = M._run_engine(eng, True, [x]).permute(0, 3, 1, 2)
+    close(y, _t(layer_kats[name + "/y_train"]), name + " y_train")
+    labels = eng._last[0].fwd.labels(eng.handle)
+    assert any(l.startswith("conv_first") for l in labels), labels
+    y.backward(_t(layer_kats[name + "/gy"]).to(DEV))
+    torch.cuda.synchronize()
+    assert any(l.startswith("wgrad_first") for l in eng._last[0].bwd.labels(eng.handle))
+    for k, p in mod.named_parameters():
+        close(p.grad, _t(layer_kats["%s/g/%s" % (name, k)]), "%s grad %s" % (name, k), floor=1.0)
+    close(mod.bn.running_mean, _t(layer_kats[name + "/after/bn.running_mean"]), name + " running_mean")
+    close(mod.bn.running_var, _t(layer_kats[name + "/after/bn.running_var"]), name + " running_var")
+    mod.eval()
+    with torch.no_grad():
+        ye = M._run_engine(eng, False, [x]).permute(0, 3, 1, 2)
+    close(ye, _t(layer_kats[name + "/y_eval"]), name + " y_eval")
+
+
+def test_classifier_1x1_kat(layer_kats):
+    """UltClassifier 1x1 (model.py:403-414) as a one-node graph: logits, data / filter / bias gradients against the reference."""
+    cls = M.UltClassifier(8, 5, False)
+    cls.load_state_dict({k[len("cls/p/"):]: _t(layer_kats[k]) for k in layer_kats.files if k.startswith("cls/p/")})
+    cls = cls.to(DEV)
+    eng = _graph_engine({"inputs": [{"layout": "nhwc", "requires_grad": True}], "nodes": [cls._node(("in", 0))]}, cls)
+    x = _t(layer_kats["cls/x"]).to(DEV).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    y = M._run_engine(eng, True, [x])
+    close(y, _t(layer_kats["cls/y"]), "cls y")
+    y.backward(_t(layer_kats["cls/gy"]).to(DEV))
+    torch.cuda.synchronize()
+    close(x.grad.permute(0, 3, 1, 2), _t(layer_kats["cls/gx"]), "cls gx", floor=1.0)
+    for k, p in cls.named_parameters():
+        close(p.grad, _t(layer_kats["cls/g/" + k]), "cls grad " + k, floor=1.0)
+
+
+@pytest.mark.parametrize("first", [0, 3])
+def test_maxpool_kat(layer_kats, first):
+    """MaxPool2d(2,2) forward / backward kernels (model.py:92-103) against the reference's pool/* vectors.  The pool runs inside a
+    graph, so it is followed by a 1x1 classifier whose weights SELECT five of the eight pooled channels (exact 1.0 / 0.0): the
+    logits are then the pooled values themselves and the data gradient is the pool's own backward."""
+    cls = M.UltClassifier(8, 5, False)
+    with torch.no_grad():
+        cls.layers.Class.weight.zero_()
+        cls.layers.Class.bias.zero_()
+        for c in range(5):
+            cls.layers.Class.weight[c, first + c, 0, 0] = 1.0
+    cls = cls.to(DEV)
+    eng = _graph_engine({"inputs": [{"layout": "nhwc", "requires_grad": True}],
+                         "nodes": [{"op": "pool", "src": ("in", 0)}, cls._node(("node", 0))]}, cls)
+    x = _t(layer_kats["pool/x"]).to(DEV).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    y = M._run_engine(eng, True, [x])
+    ref_y = _t(layer_kats["pool/y"])[:, first:first + 5]
+    assert torch.equal(y.cpu(), ref_y)                              # a max and a multiplication by 1.0: bit exact
+    gy = _t(layer_kats["pool/gy"])[:, first:first + 5].contiguous()
+    y.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+    gx = x.grad.permute(0, 3, 1, 2).cpu()
+    assert torch.equal(gx[:, first:first + 5], _t(layer_kats["pool/gx"])[:, first:first + 5])
+    rest = [c for c in range(8) if not first <= c < first + 5]
+    assert float(gx[:, rest].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("name,cin,cout", [("up_16_8", 16, 8), ("up_64_32", 64, 32), ("up_128_64", 128, 64)])
@@ -154,10 +223,10 @@ def test_device_metrics_match_reference_loops():
 
 @pytest.mark.parametrize("N,H,W,dil,mode2", [(2, 37, 70, 1, "grad_enc"), (1, 19, 131, 2, "grad_dec"), (3, 8, 64, 1, "plain"),
                                               (2, 40, 129, 2, "grad_enc")])
-def test_first_layer_filter_gradient_kernels(N, H, W, dil, mode2, monkeypatch):
+def test_first_layer_filter_gradient_kernel(N, H, W, dil, mode2):
     """RCV_OP_WGRAD on the NCHW image (3 -> 8 channels: model.py:475 Level0.Conv0, PB_FCN's dilated conv0) through the C ABI: the
-    vector-ALU kernel (wgrad_first.hip) and the matrix-core kernel it replaces on this layer, both against the float64 filter
-    gradient of torch's conv2d for ragged planes; tolerance 2e-5 of the largest entry (fp32 sums over N*H*W pixels)."""
+    vector-ALU kernel (wgrad_first.hip) against the float64 filter gradient of torch's conv2d for ragged planes; tolerance 2e-5 of
+    the largest entry (fp32 sums over N*H*W pixels)."""
     from robocupvision_amd import _lib as L
     dev = torch.device("cuda:0")
     h = L.handle(0)
@@ -179,29 +248,23 @@ def test_first_layer_filter_gradient_kernels(N, H, W, dil, mode2, monkeypatch):
     out.backward(dz.permute(0, 3, 1, 2))
     modes = {"plain": L.LOAD_PLAIN, "grad_enc": L.LOAD_GRAD_ENC, "grad_dec": L.LOAD_GRAD_DEC}
     img_d, gy_d, r_d, k_d = img.to(dev), gy.to(dev), r.to(dev), k.to(dev)
-    labels = []
-    for no_first in (False, True):
-        if no_first:
-            monkeypatch.setenv("RCV_NO_WGRAD_FIRST", "1")
-        else:
-            monkeypatch.delenv("RCV_NO_WGRAD_FIRST", raising=False)
-        dw = torch.full((8, 3, 3, 3), float("nan"), device=dev)
-        db = torch.full((8,), float("nan"), device=dev)
-        op = L.make_op(L.OP_WGRAD, L.F_BIAS, n=N, h=H, w=W, cin=3, ho=H, wo=W, cout=8, stride=1, dil=dil, inmode=L.LOAD_NCHW,
-                       inmode2=modes[mode2], p_in=img_d.data_ptr(), p_in2=gy_d.data_ptr(), p_in2_aux=r_d.data_ptr(), p_in2_c=k_d.data_ptr())
-        nb = L.op_workspace(h, op)
-        part = torch.full((max(nb // 4, 4),), float("nan"), device=dev)   # rows no workgroup writes must not be read into results
-        op.p[L.RCV_P_PART] = part.data_ptr()
-        red = L.make_op(L.OP_WGRAD_REDUCE, 0, cin=3, cout=8, nsplit=op.i[L.RCV_I_NSPLIT], p_part=part.data_ptr(), p_out=dw.data_ptr(),
-                        p_bias=db.data_ptr())
-        lst = L.OpList([op, red])
-        labels.append(lst.labels(h)[0])
-        lst.run(h, torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        for got, ref, what in ((dw, w.grad, "dW"), (db, b.grad, "db")):
-            err = float((got.double().cpu() - ref).abs().max())
-            assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, (labels[-1], what, err, float(ref.abs().max()))
-    assert labels[0].startswith("wgrad_first") and labels[1].startswith("wgrad_mfma"), labels
+    dw = torch.full((8, 3, 3, 3), float("nan"), device=dev)
+    db = torch.full((8,), float("nan"), device=dev)
+    op = L.make_op(L.OP_WGRAD, L.F_BIAS, n=N, h=H, w=W, cin=3, ho=H, wo=W, cout=8, stride=1, dil=dil, inmode=L.LOAD_NCHW,
+                   inmode2=modes[mode2], p_in=img_d.data_ptr(), p_in2=gy_d.data_ptr(), p_in2_aux=r_d.data_ptr(), p_in2_c=k_d.data_ptr())
+    nb = L.op_workspace(h, op)
+    part = torch.full((max(nb // 4, 4),), float("nan"), device=dev)   # rows no workgroup writes must not be read into results
+    op.p[L.RCV_P_PART] = part.data_ptr()
+    red = L.make_op(L.OP_WGRAD_REDUCE, 0, cin=3, cout=8, nsplit=op.i[L.RCV_I_NSPLIT], p_part=part.data_ptr(), p_out=dw.data_ptr(),
+                    p_bias=db.data_ptr())
+    lst = L.OpList([op, red])
+    label = lst.labels(h)[0]
+    assert label.startswith("wgrad_first"), label
+    lst.run(h, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for got, ref, what in ((dw, w.grad, "dW"), (db, b.grad, "db")):
+        err = float((got.double().cpu() - ref).abs().max())
+        assert err <= 2e-5 * float(ref.abs().max()) + 1e-6, (label, what, err, float(ref.abs().max()))
 
 
 def test_adam_l1_named_entry_points_vs_torch():

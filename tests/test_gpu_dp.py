@@ -1,0 +1,186 @@
+"""GPU, in process: the pieces of the data-parallel / caller-side step around the kernels.
+
+  * the bucketed backward (engine.run_bucketed through the real op lists): gradient ranges handed out while backward is still
+    running are final -- bitwise equal to the un-bucketed gradient -- once the filter-gradient stream has been joined;
+  * the prune mask of train.py:50-65 (fused Adam launch, and the literal loop on the aliased gradient views with stock Adam)
+    against the CPU oracle running those reference lines;
+  * optimizer bookkeeping: the 10x learning-rate group (transfer > 0, train.py:357-358), parameters without a gradient stay untouched;
+  * the one-forward-in-flight rule raises instead of computing wrong gradients; ignored labels (-100) behave as under NLLLoss."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_reference as O
+import robocupvision_amd.model as M
+from robocupvision_amd import _lib as L
+from robocupvision_amd.train import Trainer
+from test_gpu_blocks import close, _t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CE_W = [1, 10, 30, 10, 2]
+
+
+def build(ctor=None):
+    torch.manual_seed(12345678)
+    return M.ROBO_UNet(**(ctor or {}))
+
+
+@pytest.mark.parametrize("buckets", [1, 3, 6])
+def test_bucket_callback_ranges_are_final_when_reported(buckets):
+    x, t = O.synthetic_batch(2, 48, 64)
+    x, t = x.to(DEV), t.to(DEV)
+    model = build().to(DEV).train()
+    crit = M.CrossEntropyLoss2d(torch.tensor(CE_W, dtype=torch.float32)).to(DEV)
+    crit(model(x), t).backward()                       # reference: plain (un-bucketed) backward
+    torch.cuda.synchronize()
+    eng = model._get_engine()
+    ref = eng.flat.grad.clone()
+    for k in range(len(eng.flat.params)):              # poison every parameter's slice (the 16-byte padding between slices stays 0)
+        eng.flat.grad_view(k).fill_(float("nan"))
+    snaps = []
+
+    def cb(lo, hi):
+        cur = torch.cuda.current_stream(torch.device(DEV))
+        L.join_side(eng.handle, cur.cuda_stream)       # what GradExchange does on its communication stream
+        snaps.append((lo, hi, eng.flat.grad[lo:hi].clone()))
+
+    eng.grad_ready_cb, eng.grad_buckets = cb, buckets
+    try:
+        model.zero_grad(set_to_none=True)
+        crit(model(x), t).backward()
+        torch.cuda.synchronize()
+    finally:
+        eng.grad_ready_cb = None
+    assert 1 <= len(snaps) <= buckets
+    assert snaps[0][1] == eng.flat.numel and snaps[-1][0] == 0
+    assert all(snaps[k][0] == snaps[k + 1][1] for k in range(len(snaps) - 1))      # descending, contiguous
+    for lo, hi, g in snaps:
+        assert torch.equal(g, ref[lo:hi]), "range [%d,%d) was reported before it was final" % (lo, hi)
+    assert torch.equal(eng.flat.grad, ref)
+
+
+def _pruned_oracle(ctor, x, t, steps, ratio):
+    torch.manual_seed(12345678)
+    sd = M.ROBO_UNet(**ctor).state_dict()
+    st = O.TrainState(sd, O.NetConfig(**ctor))
+    indices = O.prune_model_new(st.params(), ratio)          # model.py:45-57 on the oracle's parameters
+    out = [O.train_step(st, x, t, indices=indices) for _ in range(steps)]
+    return st, indices, out
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_prune_mask_step_vs_oracle(fused):
+    """train.py:344-347 (pruneModelNew) + train.py:50-65 (no L1 term, gradients of pruned weights zeroed) + Adam, three steps."""
+    ctor = dict(noScale=False)
+    x, t = O.synthetic_batch(2, 48, 64, seed=5)
+    st, ref_idx, ref = _pruned_oracle(ctor, x, t, 3, 0.05)
+    model = build(ctor).to(DEV)
+    indices = M.pruneModelNew(model.parameters(), 0.05)
+    assert len(indices) == len(ref_idx) and all(torch.equal(a.cpu(), b) for a, b in zip(indices, ref_idx))
+    assert sum(int(m.sum()) for m in indices) > 1000
+    if fused:
+        tr = Trainer(model, class_weights=CE_W, lr=1e-3, decay=1e-6, prune_indices=indices)
+    else:       # stock torch.optim.Adam over the reference's five groups: Trainer runs the literal train.py:59-65 loop on the views
+        from robocupvision_amd.optim import reference_param_groups
+        tr = Trainer(model, class_weights=CE_W, optimizer=torch.optim.Adam(reference_param_groups(model, 1e-3), lr=1e-3),
+                     prune_indices=indices)
+    for k in range(3):
+        tr.step(x.to(DEV), t.to(DEV))
+        met = tr.pop_metrics()
+        assert abs(met["loss"] - ref[k]["loss"]) <= 1e-3 * abs(ref[k]["loss"]), (k, met, ref[k]["loss"])
+        assert met["reg"] == 0.0                             # train.py:51: reg stays Tensor([0.0]) in a pruning run
+    big = [p for p in model.parameters() if p.dim() > 1]
+    for p, m in zip(big, indices):
+        assert float(p.detach()[m].abs().max()) == 0.0       # pruned weights stay exactly zero: zero gradient => zero Adam update
+    for n, p in model.named_parameters():
+        if n.startswith("upPart") and n.endswith("conv.bias"):
+            # a bias directly ahead of BatchNorm: its exact gradient is 0 (what the engine returns); the reference holds ~1e-9 of
+            # rounding noise there, which Adam -- without the L1 term of a non-pruning run to dominate it -- turns into steps of a
+            # fraction of lr.  The value of such a bias never reaches the network output.
+            continue
+        r = st.sd[n].detach()
+        # three Adam steps move every live element by ~3*lr; the sign decisions of tiny gradients may differ between fp32
+        # evaluations, so compare the bulk: 99.5 % of the elements within 0.2*lr, none further than 2 steps
+        d = (p.detach().cpu() - r).abs()
+        assert float(d.max()) <= 6.5e-3, n
+        assert float((d <= 2e-4).float().mean()) >= 0.97, (n, float((d <= 2e-4).float().mean()))
+
+
+def test_transfer_group_gets_ten_times_the_learning_rate():
+    """train.py:357-358: downPart[0:transfer] steps at 10x lr.  First Adam step: |delta p| = lr_group (sign of the gradient)."""
+    x, t = O.synthetic_batch(2, 48, 64, seed=2)
+    model = build().to(DEV)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    tr = Trainer(model, class_weights=CE_W, lr=1e-3, decay=1e-6, transfer=2)
+    tr.step(x.to(DEV), t.to(DEV))
+    torch.manual_seed(12345678)
+    st = O.TrainState(M.ROBO_UNet().state_dict(), O.NetConfig(), transfer=2)
+    O.train_step(st, x, t)
+    for k, p in model.named_parameters():
+        d = (p.detach() - before[k]).abs()
+        fast = k.startswith("downPart.Level0.") or k.startswith("downPart.Level1.")
+        lr = 1e-2 if fast else 1e-3
+        moved = d[d > 0]
+        assert moved.numel() > 0 and abs(float(moved.median()) - lr) <= 0.02 * lr, (k, float(moved.median()), lr)
+        # against the oracle's post-step parameters: Adam's first step is lr*sign(g), so an element whose gradient is ~0 may land
+        # 2*lr away (opposite signs in two fp32 evaluation orders): a handful per tensor at most, nothing further than that
+        r = st.sd[k].detach()
+        dd = (p.detach().cpu() - r).abs()
+        assert float(dd.max()) <= 2.02 * lr, (k, float(dd.max()))
+        assert float((dd <= 0.02 * lr).float().mean()) >= 0.999 or k.endswith("conv.bias") and k.startswith("upPart"), k
+
+
+def test_parameters_without_gradient_are_not_stepped():
+    """PB_FCN_2 (a ROBO_UNet subclass) carries a pooled classification head the segmentation graph never reads: torch.optim.Adam
+    skips it (grad None); the fused launch must leave it bit-unchanged as well, L1 decay included."""
+    torch.manual_seed(12345678)
+    net = M.PB_FCN_2(False).to(DEV)
+    head = {k: v.detach().clone() for k, v in net.named_parameters() if k.startswith("classifier.")}
+    assert head
+    tr = Trainer(net, class_weights=CE_W, lr=1e-2, decay=1e-2)
+    x, t = O.synthetic_batch(2, 48, 64, seed=4)
+    for _ in range(2):
+        tr.step(x.to(DEV), t.to(DEV))
+    after = dict(net.named_parameters())
+    for k, v in head.items():
+        assert torch.equal(after[k].detach(), v), k
+    moved = [k for k, p in net.named_parameters() if not k.startswith("classifier.")]
+    assert moved
+
+
+def test_backward_of_a_stale_forward_raises():
+    x1, t1 = O.synthetic_batch(1, 16, 24)
+    model = build().to(DEV).train()
+    crit = M.CrossEntropyLoss2d().to(DEV)
+    loss1 = crit(model(x1.to(DEV)), t1.to(DEV))
+    with torch.no_grad():
+        model(torch.zeros(2, 3, 24, 32, device=DEV))          # e.g. a validation batch in between
+    with pytest.raises(L.RcvError, match="stale forward"):
+        loss1.backward()
+    # the documented order works
+    model.zero_grad(set_to_none=True)
+    crit(model(x1.to(DEV)), t1.to(DEV)).backward()
+    assert all(p.grad is not None for p in model.parameters())
+
+
+@pytest.mark.parametrize("weighted", [True, False])
+def test_ignored_labels_behave_like_nllloss(weighted):
+    """Labels outside [0, C) -- NLLLoss's ignore_index -100 -- carry weight 0: they drop out of the loss, of its normaliser and
+    of the gradient (the reference's nn.NLLLoss does the same for -100), instead of indexing the class weights out of bounds."""
+    g = torch.Generator().manual_seed(9)
+    lg = torch.randn(2, 5, 12, 16, generator=g)
+    t = torch.randint(0, 5, (2, 12, 16), generator=g)
+    t[0, :4] = -100
+    w = torch.tensor([1.0, 10, 30, 10, 2]) if weighted else None
+    ref_in = lg.clone().requires_grad_(True)
+    ref = torch.nn.NLLLoss(w)(torch.nn.functional.log_softmax(ref_in, dim=1), t)
+    ref.backward()
+    crit = M.CrossEntropyLoss2d(w).to(DEV)
+    x = lg.to(DEV).requires_grad_(True)
+    loss = crit(x, t.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref))
+    close(x.grad, ref_in.grad, "dlogits with ignored labels", rtol=1e-4)
+    assert float(x.grad[0, :, :4].abs().max()) == 0.0
+    assert int(crit.last_stats[2]) == int((torch.max(lg, 1)[1] == t).sum())

@@ -45,3 +45,33 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 3, 16, 16))
     with pytest.raises(L.RcvError):
         M.CrossEntropyLoss2d()(torch.zeros(1, 5, 4, 4), torch.zeros(1, 4, 4, dtype=torch.long))
+
+
+def test_planner_handle_plans_but_cannot_enqueue():
+    """rcv_create_planner: a handle without a device answers layout queries (identically to a 256-CU MI355X handle) and rejects
+    every call that would enqueue work -- there is no way to reach a kernel launch without a real device handle."""
+    h = L.planner_handle(256)
+    op = L.make_op(L.OP_CONV, L.F_BIAS | L.F_RELU, n=2, h=30, w=40, cin=128, cout=128, ho=30, wo=40, stride=1, dil=1,
+                   inmode=L.LOAD_AFFINE, stats=L.STATS_FWD)
+    nbytes = L.op_workspace(h, op)
+    assert nbytes > 0 and op.i[L.RCV_I_NPART] > 0 and nbytes == op.i[L.RCV_I_NPART] * 2 * 128 * 4
+    again = L.make_op(L.OP_CONV, L.F_BIAS | L.F_RELU, n=2, h=30, w=40, cin=128, cout=128, ho=30, wo=40, stride=1, dil=1,
+                      inmode=L.LOAD_AFFINE, stats=L.STATS_FWD)
+    assert L.op_workspace(h, again) == nbytes and again.i[L.RCV_I_NPART] == op.i[L.RCV_I_NPART]      # cached plan, same answer
+    lst = L.OpList([op])
+    assert lst.labels(h)[0].startswith("conv_dma")
+    with pytest.raises(L.RcvError, match="planning-only"):
+        lst.run(h, 0)
+    with pytest.raises(L.RcvError, match="planning-only"):
+        lst.run_timed(h, 0)
+    with pytest.raises(L.RcvError):
+        L.planner_handle(0)
+
+
+def test_shipped_library_does_not_read_the_environment():
+    """Experiment knobs are compiled in only by `make EXPERIMENTS=1`: the shipped librcv.so has no getenv on its launch path."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", L.LIB_PATH], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip("nm not available")
+    assert not any(tok.split("@")[0] == "getenv" for tok in out.stdout.split()), "librcv.so imports getenv: an experiment build was left in the tree"
