@@ -7,14 +7,23 @@
 
 A "step" is the body of the reference's train.py:43-74 on one synthetic batch already resident in HBM:
 zero_grad, forward (train-mode BatchNorm), weighted cross-entropy + arg-max/accuracy, backward,
-decay*L1 + Adam update.  Rank 0 prints ONE JSON line.  `roofline` describes the kernel with the largest
-share of the step (algorithmic FLOPs of its launches / their HIP-event time, rcv_run_timed, taken right
-after the timed region on the same inputs); `cpu_baseline` is the CPU oracle (oracle/cpu_reference.py:
-the reference's own operator sequence on stock PyTorch CPU kernels) timed on this host on a bounded sample.
+decay*L1 + Adam update.  Rank 0 prints ONE JSON line.
+
+`roofline` describes the kernel family with the largest share of the step: its algorithmic FLOPs and bytes (engine.op_work: SURVEY
+8(d)'s per-layer figures) over the HIP-event time of its launches (rcv_run_timed on the stream the kernels run on, taken right after
+the timed region on the same buffers).  The roof is chosen per kernel from its arithmetic intensity: fp32-MFMA peak when
+FLOPs/157.3T >= bytes/8T, HBM otherwise.  `t_roof_ms` = sum over ALL ops of the step of max(FLOPs/peak, bytes/HBM peak) -- the
+per-layer roofline of SURVEY 8(d) -- and `step_frac` = t_roof_ms / ms_per_step.  `cpu_baseline` is the CPU oracle
+(oracle/cpu_reference.py: the reference's own operator sequence on stock PyTorch CPU kernels) timed on this host on a bounded sample.
+
+Other workloads (--workload): BASELINE.json configs 2 (robo_unet_160x120_bs64), 3 (unet_640x480_bs32) and 5 (labelprop_160x120_b2 /
+_b64: LabelProp frame-pair inference, validLabelProp.py:132-135; a step = one forward call, latency = ms_per_step).
 """
 import argparse
+import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -36,6 +45,9 @@ WORKLOADS = {
     # --v2 (train.py:302-307): concatenated skips, 3x3 classifier, 9-conv belly of 64 planes
     "robo_unet_v2_640x480_bs32": (dict(noScale=True, planes=8, depth=4, levels=1, bellySize=9, bellyPlanes=64, v2=True, classSize=3),
                                   32, 480, 640),
+    # BASELINE config 5: LabelProp(5, 32) inference on 8-channel frame-pair inputs (labelPropTrain.py:178-182); B = 2 is one pair
+    "labelprop_160x120_b2": (None, 2, 120, 160),
+    "labelprop_160x120_b64": (None, 64, 120, 160),
 }
 
 
@@ -46,26 +58,29 @@ def synthetic(B, H, W, seed):
     return x, t
 
 
-def pmc_traffic(label):
-    """HBM bytes per launch of the kernel family `label` from the newest committed PMC pass (profiles/*_hbm_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of this same command, corrected as MI355X_MICROARCH.md
-    prescribes); None when no pass is on disk."""
-    import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+def pmc_traffic(label, workload):
+    """HBM bytes per launch of the kernel family `label` from the newest committed PMC pass of this workload
+    (profiles/*<workload>*_hbm_traffic.json, or profiles/*_hbm_traffic.json for the headline: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    in separate passes of this same command, corrected as MI355X_MICROARCH.md prescribes); None when no pass is on disk."""
+    if workload == "robo_unet_640x480_bs32":
+        files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))
+                 if not any(w in os.path.basename(f) for w in WORKLOADS if w != workload)]
+    else:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s*_hbm_traffic.json" % workload)))
     if not files:
         return None, None
     kern = json.load(open(files[-1]))["kernels"]
-    m = re.match(r"(t?conv)(m?)(s?)_(mfma|dma)<([0-9,]+)>|(wgrad)_mfma<([0-9,]+),f(\d+)>", label)
+    m = re.match(r"(t?conv)([ma]?)(s?)_(mfma|dma)<([0-9,]+)>|(wgrad)_mfma<([0-9,]+),f(\d+)>", label)
     if not m:
-        return None, None
-    if m.group(6):
+        # small kernels: the family name is a prefix of the kernel symbol (cls_fwd -> cls_fwd_kernel<...>)
+        want = lambda k: k.startswith(label + "_kernel") or k.startswith(label.split("<")[0] + "_kernel")
+    elif m.group(6):
         base, nums = "wgrad_mfma_kernel", m.group(7).split(",") + [m.group(8)]
         want = lambda k: k.startswith(base + "<") and [x.strip() for x in k[len(base) + 1:-1].split(",")][:6] == nums
     else:
         nums = m.group(5).split(",")
         base = "convs_mfma_kernel" if m.group(3) else ("conv_dma_kernel" if m.group(4) == "dma" else "conv_mfma_kernel")
-        kind = "2" if m.group(2) else ("1" if m.group(1) == "tconv" else "0")
+        kind = {"": "1" if m.group(1) == "tconv" else "0", "m": "2", "a": "3"}[m.group(2)]
         if m.group(3):      # convs_mfma_kernel<WM, WN, CK, KIND, XMAX, TWO>
             want = lambda k: k.startswith(base + "<") and [x.strip() for x in k[len(base) + 1:-1].split(",")][:4] == nums[:3] + [kind]
         elif m.group(4) == "dma":   # conv_dma_kernel<WM, WN, WAVES_M, WAVES_N, KIND, TWO>
@@ -80,15 +95,19 @@ def pmc_traffic(label):
     return (tot / n if n else None), os.path.basename(files[-1])
 
 
-def cpu_baseline(ctor, H, W, budget_s=20.0, dice=False):
-    """The CPU oracle on this host: same step body, all host threads, bounded sample."""
-    from oracle import cpu_reference as O
+def _host_threads():
     threads = os.cpu_count() or 1
     try:
         threads = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    threads = min(threads, 16)      # the share of host cores a 1-GPU slot of the box owns (oversubscribing 256 throttles)
+    return min(threads, 16)      # the share of host cores a 1-GPU slot of the box owns (oversubscribing 256 throttles)
+
+
+def cpu_baseline(ctor, H, W, budget_s=20.0, dice=False):
+    """The CPU oracle on this host: same step body, all host threads, bounded sample."""
+    from oracle import cpu_reference as O
+    threads = _host_threads()
     old = torch.get_num_threads()
     torch.set_num_threads(threads)
     try:
@@ -114,6 +133,114 @@ def cpu_baseline(ctor, H, W, budget_s=20.0, dice=False):
         torch.set_num_threads(old)
 
 
+def cpu_baseline_labelprop(sd, B, H, W, budget_s=15.0):
+    from oracle import cpu_reference as O
+    threads = _host_threads()
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        x = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(1))
+        with torch.no_grad():
+            O.labelprop_forward(sd, x)
+            t0 = time.perf_counter()
+            n = 0
+            while True:
+                O.labelprop_forward(sd, x)
+                n += 1
+                el = time.perf_counter() - t0
+                if el > budget_s or n >= 200:
+                    break
+        return {"value": round(B * n / el, 3), "unit": "img/s", "cores": threads, "kind": "port",
+                "sample": "%d eval-mode forwards of batch %d at %dx%d, torch %s CPU, %d threads" % (n, B, W, H, torch.__version__, threads)}
+    finally:
+        torch.set_num_threads(old)
+
+
+def roofline_block(rows, ms_per_step, workload, batch_override, breakdown):
+    """Per-kernel-family table from engine.profile_last rows -> the `roofline` object (dominant family) + per-layer roofline sums."""
+    by = {}
+    for r in rows:
+        a = by.setdefault(r["label"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+        a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
+    total_ms = sum(a["ms"] for a in by.values())
+    bound_ms = lambda fl, by_: max(fl / (PEAK_FP32_MFMA_TFLOPS * 1e9), by_ / (PEAK_HBM_GBS * 1e6))
+    t_roof = sum(bound_ms(r["flops"], r["bytes"]) for r in rows)
+    dom = max(by, key=lambda k: by[k]["ms"])
+    d = by[dom]
+    mfma_bound = d["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12) >= d["bytes"] / (PEAK_HBM_GBS * 1e9)
+    tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+    gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+    out = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom,
+           "achieved": round(tf if mfma_bound else gbs, 3), "peak": PEAK_FP32_MFMA_TFLOPS if mfma_bound else PEAK_HBM_GBS,
+           "unit": "TFLOP/s" if mfma_bound else "GB/s",
+           "frac": round((tf / PEAK_FP32_MFMA_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS), 4), "traffic": None,
+           "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+           "share_of_kernel_time": round(d["ms"] / total_ms, 4),
+           "algorithmic_tflops": round(tf, 3), "algorithmic_gbs": round(gbs, 1),
+           "arithmetic_intensity_flop_per_byte": round(d["flops"] / d["bytes"], 2) if d["bytes"] else None,
+           "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"])}
+    tr, src = pmc_traffic(dom, workload) if not batch_override else (None, None)
+    if tr is not None:
+        out["traffic"] = int(tr)
+        out["traffic_source"] = "profiles/" + src
+    out["t_roof_ms"] = round(t_roof, 4)
+    out["step_frac"] = round(t_roof / ms_per_step, 4) if ms_per_step > 0 else None
+    out["step_tflops"] = round(sum(a["flops"] for a in by.values()) / (ms_per_step * 1e-3) / 1e12, 3)
+    out["step_hbm_gbs_algorithmic"] = round(sum(a["bytes"] for a in by.values()) / (ms_per_step * 1e-3) / 1e9, 1)
+    out["sum_kernel_ms"] = round(total_ms, 4)
+    if breakdown:
+        for k in sorted(by, key=lambda k: -by[k]["ms"]):
+            a = by[k]
+            tfk = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0
+            gb = a["bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0
+            lb = sum(bound_ms(r["flops"], r["bytes"]) for r in rows if r["label"] == k)
+            print("%-28s launches %3d  ms %8.3f  %5.1f%%  %7.2f TF/s  %8.1f GB/s  of its roof %5.2f" %
+                  (k, a["launches"], a["ms"], 100 * a["ms"] / total_ms, tfk, gb, lb / a["ms"] if a["ms"] > 0 else 0), file=sys.stderr)
+        if os.environ.get("RCV_BENCH_ROWS"):
+            # per op: measured vs the per-op roofline bound max(FLOP/157.3T, bytes/8T); sorted by the gap
+            for r in sorted(rows, key=lambda r: -(r["ms"] - bound_ms(r["flops"], r["bytes"]))):
+                lb = bound_ms(r["flops"], r["bytes"])
+                print("%s %-26s %-24s ms %7.4f  bound %7.4f  gap %7.4f  %6.2f TF/s %7.1f GB/s" %
+                      ("B" if r["bwd"] else "F", r["label"], r["shape"], r["ms"], lb, r["ms"] - lb, r["flops"] / max(r["ms"], 1e-9) / 1e9,
+                       r["bytes"] / max(r["ms"], 1e-9) / 1e6), file=sys.stderr)
+            print("sum of per-op bounds %.3f ms, sum of kernel times %.3f ms" % (t_roof, total_ms), file=sys.stderr)
+    return out
+
+
+def run_labelprop(args, dev, rank, world):
+    import robocupvision_amd.model as M
+    _, B, H, W = WORKLOADS[args.workload]
+    if args.batch:
+        B = args.batch
+    torch.manual_seed(12345678)
+    net = M.LabelProp(5, 32, 0.0)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(dev).eval()
+    x = torch.randn(B, 8, H, W, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            net(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            net(x)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    ms = 1e3 * elapsed / args.steps
+    out = {"metric": "inference images/sec, LabelProp 160x120 8-channel frame-pair inputs, B=%d" % B,
+           "value": round(B * world * args.steps / elapsed, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": args.workload, "per_gpu_batch": B, "height": H, "width": W,
+                      "step": "one eval-mode forward call (validLabelProp.py:132-135), NCHW in -> logits", "latency_ms": round(ms, 4),
+                      "parallelism": "replicas%d" % world, "weights": "seeded random init (the shipped .pth does not travel)"}}
+    if rank == 0 and not args.no_roofline:
+        rows = net.__dict__["_engine"].profile_last(reps=5)
+        out["roofline"] = roofline_block(rows, ms, args.workload, args.batch, args.breakdown)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_labelprop(sd, B, H, W)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +249,9 @@ def main():
     ap.add_argument("--workload", default="robo_unet_640x480_bs32", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch size")
     ap.add_argument("--dice", action="store_true", help="train with DiceLoss (train.py --useDice) instead of the cross entropy")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the whole training step as ONE captured hipGraph (Trainer.capture); "
+                    "0 (default): eager.  Measured on robo_unet_160x120_bs64: 2.41 ms/step replayed vs 2.14 eager -- the step is bound by "
+                    "its chain of dependent kernels, not by the host, and the replayed graph schedules its two streams worse")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
@@ -135,6 +265,22 @@ def main():
             raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.workload.startswith("labelprop"):
+        # inference shards into independent replicas: no collective on the path, N ranks run N copies (whole-job img/s = sum)
+        out = run_labelprop(args, dev, rank, world)
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl")
+            tt = torch.tensor([out["ms_per_step"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            out["ms_per_step"] = round(float(tt.item()), 4)
+            out["value"] = round(out["config"]["per_gpu_batch"] * world / (out["ms_per_step"] * 1e-3), 2)
+            dist.barrier(device_ids=[local_rank])
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out))
+        return
     dist = None
     if world > 1 or os.environ.get("RCV_FORCE_COLLECTIVES"):
         import torch.distributed as dist
@@ -163,14 +309,20 @@ def main():
         dist.barrier(device_ids=[local_rank])
         dist.barrier(device_ids=[local_rank])
 
+    use_graph = args.graph == 1
+    step = trainer.step
+    if use_graph:
+        for _ in range(3):
+            trainer.step(x, t)                  # plans, optimizer state and the backward schedule exist before the capture
+        step = trainer.capture(x, t)            # one hipGraph launch per step from here on (same kernels, same order)
     for _ in range(args.warmup):
-        trainer.step(x, t)
+        step(x, t)
     if dist is not None:
         dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.step(x, t)
+        step(x, t)
     if dist is not None:
         dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
@@ -180,15 +332,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     metrics = trainer.pop_metrics()
+    ms_per_step = 1e3 * elapsed / args.steps
 
     out = {
         "metric": "training images/sec, ROBO-UNet 640x480 bs=32/GPU" if args.workload == "robo_unet_640x480_bs32"
         else "training images/sec, " + args.workload,
         "value": round(B * world * args.steps / elapsed, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
                    "step": "fwd+CE/argmax+bwd+L1+Adam (train.py:43-74)", "parallelism": "dp%d" % world,
+                   "launch": "one captured hipGraph per step" if use_graph else "eager (one rcv_run per pass)",
                    "loss_after": round(metrics["loss"], 6)},
     }
 
@@ -199,46 +353,11 @@ def main():
         if plans[0].side_ms:
             out["config"]["backward_ms_two_streams_vs_one"] = [round(v, 3) for v in plans[0].side_ms]
     if rank == 0 and not args.no_roofline:
-        rows = model._get_engine().profile_last(reps=3)
-        by = {}
-        for r in rows:
-            a = by.setdefault(r["label"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
-            a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
-        total_ms = sum(a["ms"] for a in by.values())
-        dom = max(by, key=lambda k: by[k]["ms"])
-        d = by[dom]
-        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                           "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                           "share_of_kernel_time": round(d["ms"] / total_ms, 4),
-                           "algorithmic_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1) if d["ms"] > 0 else 0.0}
-        # the committed PMC pass is of the default workload: per-launch traffic of other shapes is not on disk
-        tr, src = pmc_traffic(dom) if args.workload == "robo_unet_640x480_bs32" and not args.batch else (None, None)
-        if tr is not None:
-            out["roofline"]["traffic"] = int(tr)
-            out["roofline"]["traffic_source"] = "profiles/" + src
-            out["roofline"]["algorithmic_bytes_per_launch"] = int(d["bytes"] / d["launches"])
-        mf = sum(a["flops"] for a in by.values())
-        out["roofline"]["step_tflops"] = round(mf / (total_ms * 1e-3) / 1e12, 3)
-        out["roofline"]["sum_kernel_ms"] = round(total_ms, 4)
-        if args.breakdown:
-            for k in sorted(by, key=lambda k: -by[k]["ms"]):
-                a = by[k]
-                tf = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0
-                gb = a["bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0
-                print("%-28s launches %3d  ms %8.3f  %5.1f%%  %7.2f TF/s  %8.1f GB/s" %
-                      (k, a["launches"], a["ms"], 100 * a["ms"] / total_ms, tf, gb), file=sys.stderr)
-            if os.environ.get("RCV_BENCH_ROWS"):
-                # per op: measured vs the per-op roofline bound max(FLOP/157.3T, bytes/8T); sorted by the gap
-                tot_gap = 0.0
-                for r in sorted(rows, key=lambda r: -(r["ms"] - max(r["flops"] / 157.3e9, r["bytes"] / 8e9))):
-                    lb = max(r["flops"] / 157.3e9, r["bytes"] / 8e9)
-                    tot_gap += r["ms"] - lb
-                    print("%s %-26s %-24s ms %7.4f  bound %7.4f  gap %7.4f  %6.2f TF/s %7.1f GB/s" %
-                          ("B" if r["bwd"] else "F", r["label"], r["shape"], r["ms"], lb, r["ms"] - lb, r["flops"] / max(r["ms"], 1e-9) / 1e9,
-                           r["bytes"] / max(r["ms"], 1e-9) / 1e6), file=sys.stderr)
-                print("sum of per-op bounds %.3f ms, sum of gaps %.3f ms" % (sum(r["ms"] for r in rows) - tot_gap, tot_gap), file=sys.stderr)
+        rows = eng.profile_last(reps=3)
+        # the optimizer launch belongs to the step as well (one RCV_OP_ADAM_L1 over the flat buffers: 28 B per parameter)
+        n_par = eng.flat.numel
+        rows.append({"label": "adam_l1", "kind": 16, "ms": 0.0, "flops": 0.0, "bytes": 28.0 * n_par, "shape": "%d parameters" % n_par, "bwd": True})
+        out["roofline"] = roofline_block(rows, ms_per_step, args.workload, args.batch, args.breakdown)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctor, H, W, dice=args.dice)
     if rank == 0:

@@ -275,7 +275,9 @@ int rcv_confusion(rcv_handle* h, const uint8_t* argmax, const int64_t* target, i
 int rcv_sgd_step(rcv_handle* h, float* param, const float* grad, float* momentum_buf, const float* lr_elem /*may be NULL*/,
                  int64_t n, float lr, float momentum, float weight_decay, int step, float grad_scale, void* stream);
 
-/* lr_elem (may be NULL): per-element learning rate; 0 = the element is not stepped at all (a parameter without a gradient).
+/* As an op record, p[RCV_P_IN_AUX] (may be NULL) is a device int32 holding the 1-based step number: it overrides `step` (the
+ * bias corrections are then formed on the device), so that a captured graph of the whole training step can be replayed.
+ * lr_elem (may be NULL): per-element learning rate; 0 = the element is not stepped at all (a parameter without a gradient).
  * As an op record, p[RCV_P_X5] (may be NULL) is the prune mask of train.py:59-65 (`param.grad[indices] = 0` after backward):
  * uint8 per element of the flat buffer, non-zero = the whole gradient of that element (L1 part included) is zero this step. */
 int rcv_adam_l1_step(rcv_handle* h, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

@@ -753,8 +753,18 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dp, const float* __res
 template <bool MET>
 __global__ void adam_l1_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                const float* __restrict__ lr_elem, size_t n, float lr, float b1, float b2, float eps, float decay,
-                               float grad_scale, float bc1, float bc2_sqrt, double* part, const float* __restrict__ loss_stats,
-                               double* metrics, const uint8_t* __restrict__ prune) {
+                               float grad_scale, int step_host, const int* __restrict__ step_dev, double* part,
+                               const float* __restrict__ loss_stats, double* metrics, const uint8_t* __restrict__ prune) {
+  // bias corrections of step t (1-based): t comes from the record, or -- when the whole training step is replayed as a captured
+  // graph and the host cannot change launch arguments -- from a device counter the caller advances ahead of this launch
+  __shared__ float s_bc[2];
+  if (threadIdx.x == 0) {
+    const int t = step_dev ? *step_dev : step_host;
+    s_bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+    s_bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+  }
+  __syncthreads();
+  const float bc1 = s_bc[0], bc2_sqrt = s_bc[1];
   float asum = 0.f;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
     const float pv = p[e];
@@ -1143,22 +1153,21 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
         return RCV_OK;
       }
       const int step = op->i[RCV_I_AUX0];
-      RCV_CHECK_ARG(n > 0 && step >= 1 && op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_X0] && op->p[RCV_P_X1], "adam: bad operand");
+      const int* step_dev = (const int*)op->p[RCV_P_IN_AUX];
+      RCV_CHECK_ARG(n > 0 && (step >= 1 || step_dev) && op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_X0] && op->p[RCV_P_X1], "adam: bad operand");
       const float b1 = op->f[1], b2 = op->f[2];
-      const float bc1 = (float)(1.0 - pow((double)b1, (double)step));
-      const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)step));
       const int g = stream_grid(h, n, 256);
       double* part = (double*)op->p[RCV_P_PART];
       if (op->p[RCV_P_X3]) {
         RCV_CHECK_ARG(part && op->p[RCV_P_X4] && op->i[RCV_I_NPART] == g, "adam + metrics: needs loss stats and a %d-row workspace (rcv_op_workspace)", g);
         hipLaunchKernelGGL(adam_l1_kernel<true>, dim3(g), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
                            (float*)op->p[RCV_P_X0], (float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], n, op->f[0], b1, b2, op->f[3],
-                           op->f[4], op->f[5], bc1, bc2s, part, (const float*)op->p[RCV_P_X4], (double*)op->p[RCV_P_X3],
+                           op->f[4], op->f[5], step, step_dev, part, (const float*)op->p[RCV_P_X4], (double*)op->p[RCV_P_X3],
                            (const uint8_t*)op->p[RCV_P_X5]);
       } else {
         hipLaunchKernelGGL(adam_l1_kernel<false>, dim3(g), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
                            (float*)op->p[RCV_P_X0], (float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], n, op->f[0], b1, b2, op->f[3],
-                           op->f[4], op->f[5], bc1, bc2s, (double*)nullptr, (const float*)nullptr, (double*)nullptr,
+                           op->f[4], op->f[5], step, step_dev, (double*)nullptr, (const float*)nullptr, (double*)nullptr,
                            (const uint8_t*)op->p[RCV_P_X5]);
       }
       break;

@@ -40,9 +40,17 @@ class AdamL1(torch.optim.Optimizer):
         self._lr_elem = None
         self._lr_key = None
         self._met_ws: Optional[torch.Tensor] = None
+        self._step_dev: Optional[torch.Tensor] = None     # device step counter (graph replay), see use_device_step()
         self._prune_src = None            # list of boolean masks (parameters with dim() > 1, parameters() order) or None
         self._prune_flat: Optional[torch.Tensor] = None
         super().__init__(reference_param_groups(model, lr, transfer), dict(lr=lr, betas=betas, eps=eps))
+
+    def use_device_step(self):
+        """Keep the Adam step number in a device int32 that every step() advances with a stream-ordered add and the launch reads
+        (RCV_OP_ADAM_L1 p[IN_AUX]): the step can then be captured once and replayed as a hipGraph (Trainer.capture)."""
+        if self._step_dev is None:
+            _, fl = self._flat()
+            self._step_dev = torch.full((1,), self._t, dtype=torch.int32, device=fl.data.device)
 
     def set_prune_mask(self, masks):
         """train.py:50-65 inside the fused step: ``masks`` = pruneModelNew(model.parameters()) (True = pruned weight).  As in
@@ -105,10 +113,13 @@ class AdamL1(torch.optim.Optimizer):
                 self._prune_flat = t
             prune_ptr = self._prune_flat.data_ptr()
         self._t += 1
+        if self._step_dev is not None:
+            self._step_dev.add_(1)
         b1, b2 = self.defaults["betas"]
         op = L.make_op(L.OP_ADAM_L1, 0, count=fl.numel, aux0=self._t, f0=lrs[0][0], f1=b1, f2=b2, f3=self.defaults["eps"],
                        f4=(0.0 if self._prune_src is not None else self.decay), f5=self.grad_scale, p_in=fl.data.data_ptr(), p_in2=fl.grad.data_ptr(),
-                       p_x0=self._m.data_ptr(), p_x1=self._v.data_ptr(), p_x2=lr_elem_ptr, p_x5=prune_ptr)
+                       p_x0=self._m.data_ptr(), p_x1=self._v.data_ptr(), p_x2=lr_elem_ptr, p_x5=prune_ptr,
+                       p_in_aux=(self._step_dev.data_ptr() if self._step_dev is not None else 0))
         if metrics is not None:
             if loss_stats is None or metrics.dtype != torch.float64 or metrics.numel() < 4 or loss_stats.dtype != torch.float32 \
                     or loss_stats.numel() < 3 or not metrics.is_cuda or not loss_stats.is_cuda:
@@ -118,6 +129,7 @@ class AdamL1(torch.optim.Optimizer):
                 self._met_ws = torch.zeros((nbytes + 7) // 8, dtype=torch.float64, device=fl.data.device)
             op.p[L.RCV_P_X3], op.p[L.RCV_P_X4], op.p[L.RCV_P_PART] = metrics.data_ptr(), loss_stats.data_ptr(), self._met_ws.data_ptr()
         L.OpList([op]).run(eng.handle, torch.cuda.current_stream(fl.data.device).cuda_stream)
+        eng.params_dirty = True
 
     def l1_term(self) -> torch.Tensor:
         """decay * sum|p| (what train.py:53 logs as `reg`), one reduction over the flat buffer."""
@@ -169,3 +181,4 @@ class SGD(torch.optim.Optimizer):
         op = L.make_op(L.OP_SGD, 0, count=fl.numel, aux0=self._t, f0=lr, f1=g["momentum"], f2=g["weight_decay"], f5=self.grad_scale,
                        p_in=fl.data.data_ptr(), p_in2=fl.grad.data_ptr(), p_x0=self._buf.data_ptr(), p_x2=lr_elem_ptr)
         L.OpList([op]).run(eng.handle, torch.cuda.current_stream(fl.data.device).cuda_stream)
+        eng.params_dirty = True

@@ -195,6 +195,40 @@ class Trainer:
             opt.step()
         return pred
 
+    def capture(self, imgs: torch.Tensor, targets: torch.Tensor):
+        """Capture ONE whole training step (forward, loss, backward on both streams, optimizer + metrics) as a hipGraph and return
+        ``step_fn(imgs, targets)`` that replays it: one graph launch per step instead of ~10 host calls enqueuing ~150 kernels --
+        what the short steps (160x120: 2 ms of GPU work) need to stay GPU bound.  Same kernels in the same order on the same
+        buffers, so results are those of ``step``.  Call after a few eager steps (plans, optimizer state and the measured backward
+        schedule exist then).  The learning rate is baked in: capture again after a scheduler changed it.  Single GPU only."""
+        if self.exchange is not None:
+            raise L.RcvError("Trainer.capture: data-parallel steps run eagerly (the RCCL all-reduces are not captured)")
+        opt = self.optimizer
+        if not isinstance(opt, AdamL1):
+            raise L.RcvError("Trainer.capture needs the fused AdamL1 optimizer")
+        eng = self.model._get_engine()
+        if eng.flat is None:
+            self.step(imgs, targets)
+        static_x, static_t = imgs.detach().clone(), targets.detach().to(torch.int64).clone()
+        opt.use_device_step()
+        self.step(static_x, static_t)                   # everything the step touches is allocated before the capture
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            pred = self.step(static_x, static_t)
+        opt._t -= 1                                     # the capture recorded the step, it did not run it
+
+        def step_fn(x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+            if x.data_ptr() != static_x.data_ptr():
+                static_x.copy_(x)
+            if t.data_ptr() != static_t.data_ptr():
+                static_t.copy_(t)
+            graph.replay()
+            opt._t += 1
+            return pred
+        step_fn.graph = graph
+        return step_fn
+
     @torch.no_grad()
     def evaluate(self, imgs: torch.Tensor, targets: torch.Tensor):
         """valid() forward (train.py:102-131): eval-mode BN, CE, arg-max mask."""

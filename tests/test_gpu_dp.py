@@ -184,3 +184,71 @@ def test_ignored_labels_behave_like_nllloss(weighted):
     close(x.grad, ref_in.grad, "dlogits with ignored labels", rtol=1e-4)
     assert float(x.grad[0, :, :4].abs().max()) == 0.0
     assert int(crit.last_stats[2]) == int((torch.max(lg, 1)[1] == t).sum())
+
+
+def test_captured_step_replays_bit_identically():
+    """Trainer.capture: the whole step as ONE hipGraph launch (forward, loss, backward on two streams, Adam + metrics with the step
+    number on the device).  Five replayed steps against five eager steps from the same state: bit-identical parameters, BatchNorm
+    buffers and metrics."""
+    x, t = O.synthetic_batch(4, 48, 64, seed=6)
+    x, t = x.to(DEV), t.to(DEV)
+    x2, t2 = O.synthetic_batch(4, 48, 64, seed=8)
+    x2, t2 = x2.to(DEV), t2.to(DEV)
+    out = []
+    for graph in (False, True):
+        model = build().to(DEV)
+        tr = Trainer(model, class_weights=CE_W, lr=1e-3, decay=1e-6)
+        for _ in range(3):
+            tr.step(x, t)
+        tr.optimizer.use_device_step()                 # (both runs read the step number from the device: same arithmetic)
+        if graph:
+            tr.step(x, t)                              # capture() runs one eager step itself: the eager run takes it here
+            step = tr.step
+        else:
+            step = tr.capture(x, t)
+        tr.pop_metrics()
+        for k in range(5):
+            step(x2 if k % 2 else x, t2 if k % 2 else t)
+        torch.cuda.synchronize()
+        out.append((tr.pop_metrics(), {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    (ma, sa), (mb, sb) = out
+    assert ma == mb, (ma, mb)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
+def test_eval_head_is_cached_and_invalidated():
+    """Inference skips the parameter-only head of the forward list (filter repack, BatchNorm constants) while nothing wrote the
+    parameters -- and must notice every way they can change: a train-mode forward (running statistics), an optimizer launch of
+    this package, load_state_dict / in-place torch ops."""
+    x, t = O.synthetic_batch(2, 48, 64, seed=3)
+    x, t = x.to(DEV), t.to(DEV)
+    model = build().to(DEV)
+    tr = Trainer(model, class_weights=CE_W, lr=1e-2, decay=1e-6)
+
+    def eval_logits():
+        model.eval()
+        with torch.no_grad():
+            return model(x).clone()
+
+    def fresh_logits():            # the same parameters through a brand-new engine: nothing cached
+        torch.manual_seed(0)
+        m2 = M.ROBO_UNet().to(DEV)
+        m2.load_state_dict(model.state_dict())
+        m2.eval()
+        with torch.no_grad():
+            return m2(x).clone()
+
+    a = eval_logits()
+    eng = model._get_engine()
+    plan = eng._last[0]
+    assert plan.n_head >= 2 and not eng.params_dirty
+    assert torch.equal(eval_logits(), a) and torch.equal(a, fresh_logits())
+    tr.step(x, t)                                      # parameters and running statistics change through kernels
+    b = eval_logits()
+    assert not torch.equal(a, b) and torch.equal(b, fresh_logits())
+    with torch.no_grad():
+        model.segmenter.layers.Class.bias.add_(1.0)    # a torch in-place op (what load_state_dict does): version counter
+        model.downPart.Level0.layers.Conv0.bn.running_var.mul_(2.0)
+    c = eval_logits()
+    assert not torch.equal(b, c) and torch.equal(c, fresh_logits())
