@@ -433,7 +433,7 @@ typedef const __attribute__((address_space(1))) void* rcv_glb_ptr;
 #define RCV_STAMP(t) do { } while (0)
 #endif
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND, bool TWO>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND, bool TWO, int XMAX = 4>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const ConvArgs a) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int NW = NT / 64;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   const int S = a.xpitch;
   constexpr int WS = COT;                       // unpadded rows: the DMA image is lane-linear
   constexpr int C4 = COT / 4;
-  constexpr int XMAX = 4, AMAX = TWO ? XMAX : 1;
+  constexpr int AMAX = TWO ? XMAX : 1;          // XMAX: register slots of the staged input chunk ((pixel, quad) items per thread): 4, or 8 for the large stride-2 tiles
   constexpr int NTAPS_MAX = (KIND == KIND_GATHER || KIND == KIND_TALL) ? 9 : 4;
   constexpr int NPH = KIND == KIND_TALL ? 4 : 1;  // accumulator sets (output parities handled by this workgroup)
   constexpr int WBUF = NTAPS_MAX * CK * WS;     // floats per filter buffer
@@ -695,7 +695,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
         }
         if (j + 1 < 9) { tap_geom(j + 1, dy, dx, ph_next); read_tap(nxt_, wb, xb, j + 1, dy, dx); }
         if (SPREAD && j < WU) dma_one(buf ^ 1, fstep, j < WU ? j : 0);           // F(i+1), one LDS-DMA instruction per tap
-        if (SPREAD && j >= 9 - XMAX && ldx) load_slot(g + 1, j - (9 - XMAX));   // X(g+1): registers, written to LDS in the next step
+        if (SPREAD && j >= 5 && ldx) {                                           // X(g+1): registers, written to LDS in the next step
+#pragma unroll
+          for (int q = 0; q < XMAX / 4; ++q) load_slot(g + 1, (j - 5) * (XMAX / 4) + q);
+        }
         mfma_tap(cur, ph);
         ph = ph_next;
         if (N_M < N_D + 2) {
@@ -760,16 +763,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
 // --------------------------------------------------------------------------------------------
 // Host side: tiling choice and launch
 // --------------------------------------------------------------------------------------------
-template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND, int XMAX = 4>
 static int launch_dma(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s, int dev) {
   const bool two = a.in_mode == RCV_LOAD_GRAD_ENC || a.in_mode == RCV_LOAD_GRAD_DEC;
   if (two) {
-    auto kern = conv_dma_kernel<WM, WN, WAVES_M, WAVES_N, KIND, true>;
+    auto kern = conv_dma_kernel<WM, WN, WAVES_M, WAVES_N, KIND, true, XMAX>;
     static size_t configured[RCV_MAX_DEVICES];
     RCV_ENSURE_LDS(kern, lds, dev, configured);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, a);
   } else {
-    auto kern = conv_dma_kernel<WM, WN, WAVES_M, WAVES_N, KIND, false>;
+    auto kern = conv_dma_kernel<WM, WN, WAVES_M, WAVES_N, KIND, false, XMAX>;
     static size_t configured[RCV_MAX_DEVICES];
     RCV_ENSURE_LDS(kern, lds, dev, configured);
     hipLaunchKernelGGL(kern, grid, dim3(WAVES_M * WAVES_N * 64), lds, s, a);
@@ -829,25 +832,36 @@ static int launch_tile(int tile, const ConvArgs& a, dim3 grid, size_t lds, hipSt
 
 // R rows x Wt cols with R*Wt <= PIX and the staged input tile within `cap` pixels.
 static bool plan_tile(int kind, int TH, int TW, int PIX, int s, int d, int cap, int* R, int* Wt, int* tiles_x, int* tiles_y) {
+  // Tiles of the LDS-DMA kernel carry a cap on their staged input pixels: the widest row segment may then only fit with few rows
+  // (a stride-2 tile of 1 x 80 outputs stages 3 x 161 inputs, 2 x 40 stages 5 x 81).  Among the segment widths that need the
+  // fewest tiles, take the one that stages the fewest input pixels; without a cap the widest segment is taken as is.
+  const bool search = cap < 65535;
+  long best_tiles = -1, best_staged = 0;
   int nx = ceil_div(TW, PIX < TW ? PIX : TW);
   for (; nx <= TW; ++nx) {
     const int wt = ceil_div(TW, nx);
+    if (search && best_tiles >= 0 && wt < 8) break;
     int r = PIX / wt;
     if (r > TH) r = TH;
     if (r < 1) continue;
-    int ih, iw;
+    int ih = 0, iw = 0;
     for (; r >= 1; --r) {
       tile_halo(kind, r, wt, s, d, &ih, &iw);
       if (ih * iw <= cap) break;
     }
     if (r < 1) continue;
     r = ceil_div(TH, ceil_div(TH, r));   // balance rows over the tiles of a column
-    *R = r; *Wt = wt;
-    *tiles_x = ceil_div(TW, wt);
-    *tiles_y = ceil_div(TH, r);
-    return true;
+    tile_halo(kind, r, wt, s, d, &ih, &iw);
+    const long tiles = (long)ceil_div(TW, wt) * ceil_div(TH, r), staged = tiles * ih * iw;
+    if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && staged < best_staged)) {
+      best_tiles = tiles; best_staged = staged;
+      *R = r; *Wt = wt;
+      *tiles_x = ceil_div(TW, wt);
+      *tiles_y = ceil_div(TH, r);
+    }
+    if (!search) return true;
   }
-  return false;
+  return best_tiles >= 0;
 }
 
 static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
@@ -884,9 +898,12 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   // candidates by (virtual) output-channel count; minimise padded work, prefer the larger tile on ties
   // LDS-DMA filter streaming pays where the filter dominates the staged bytes (wide layers); with few input
   // channels its 4-channel chunks fragment the HBM-bound input reads instead
-  const bool use_dma = mode != RCV_LOAD_NCHW && Cin >= 64 && CinP % 8 == 0 && (long long)N * H * W * Cin < (1ll << 31) && !RCV_ENV("RCV_NO_DMA");
+  // (Cin = 32 with more than 32 output channels: the 32 -> 64 stride-2 conv and its twin; staged 16 channels at a time they read
+  // 64 of the 128 bytes of a pixel record per pass instead of the 32 of the general kernel's 8-channel chunks)
+  const bool use_dma = mode != RCV_LOAD_NCHW && Cin >= 32 && CinP % 8 == 0 && (long long)N * H * W * Cin < (1ll << 31) && !RCV_ENV("RCV_NO_DMA");
   (void)Q;
   long best = -1;
+  bool best_dma = false;
   pl->tile = -1;
   for (int t = 0; t < kNumTiles; ++t) {
     const int cot = kTiles[t].cot();
@@ -900,8 +917,9 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
     int R, Wt, tx, ty;
     if (!plan_tile(pl->kind, TH, TW, kTiles[t].pix(), s, d, cap, &R, &Wt, &tx, &ty)) continue;
     const long work = (long)tx * ty * kTiles[t].pix() * round_up(pl->CoutP, cot);
-    if (best < 0 || work < best || (work == best && kTiles[t].pix() * cot > kTiles[pl->tile].pix() * kTiles[pl->tile].cot())) {
-      best = work; pl->tile = t; pl->R = R; pl->Wt = Wt; pl->tiles_x = tx; pl->tiles_y = ty;
+    const bool bigger = pl->tile >= 0 && kTiles[t].pix() * cot > kTiles[pl->tile].pix() * kTiles[pl->tile].cot();
+    if (best < 0 || work < best || (work == best && ((dma_tile && !best_dma) || (dma_tile == best_dma && bigger)))) {
+      best = work; best_dma = dma_tile; pl->tile = t; pl->R = R; pl->Wt = Wt; pl->tiles_x = tx; pl->tiles_y = ty;
     }
   }
   RCV_CHECK_ARG(pl->tile >= 0, "conv: no tile configuration for Cout=%d", Cout);
@@ -950,7 +968,8 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
       return 2 * (size_t)taps_dma * 4 * tc.cot() + 2 * (size_t)round_up(npix * conv_xpitch(xk, xs), 4) + 5 * CinP + 16 + (size_t)tc.WAVES_N * 2 * tc.cot();
     };
     const size_t lds_room = (size_t)h->max_lds / 2;
-    pl->xk = (CinP % 16 == 0 && npix * 4 <= tc.nt() * 4 && lds_floats(16) * sizeof(float) <= lds_room) ? 16 : 8;
+    const int slots = 4;                                   // (pixel, quad) register slots per thread (an 8-slot variant of the kernel for the large stride-2 tiles measured 2.6x slower)
+    pl->xk = (CinP % 16 == 0 && npix * 4 <= tc.nt() * slots && lds_floats(16) * sizeof(float) <= lds_room) ? 16 : 8;
     pl->xl_floats = round_up(npix * conv_xpitch(pl->xk, xs), 4);
     floats = 2 * (size_t)pl->wl_floats + 2 * (size_t)pl->xl_floats + 5 * CinP + 16 + (size_t)tc.WAVES_N * 2 * tc.cot();
   } else {
