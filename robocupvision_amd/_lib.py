@@ -7,7 +7,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librcv.so")
+# RCV_LIBRARY: another build of the same library (A/B timing of two builds on one GPU box, scripts/ab.sh); product code never sets it
+LIB_PATH = os.environ.get("RCV_LIBRARY") or os.path.join(_HERE, "librcv.so")
 
 RCV_I_N, RCV_I_H, RCV_I_W, RCV_I_CIN, RCV_I_COUT, RCV_I_HO, RCV_I_WO, RCV_I_STRIDE, RCV_I_DIL, \
     RCV_I_INMODE, RCV_I_INMODE2, RCV_I_STATS, RCV_I_NPART, RCV_I_NSPLIT, RCV_I_COUNT, RCV_I_AUX0, RCV_I_AUX1 = range(17)

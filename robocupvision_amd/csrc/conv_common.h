@@ -104,7 +104,10 @@ struct ConvPlan {
 // (pixel(l15) * IS * pitch + l4): 16 pixels x 2 channel lanes per 32-lane half must fall on 32 different banks.  Unit-stride pixel
 // blocks: pitch = CK + 2 (pitch/2 odd => 16 distinct even banks, + l4 the odd ones); stride-2 blocks: the lane stride is 2*pitch,
 // so pitch = CK + 1 (odd).  (CK + 1 everywhere cost 46 % of all LDS cycles in bank conflicts on the unit-stride layers.)
-static inline int conv_xpitch(int CK, int pixel_stride) { return pixel_stride == 1 ? CK + 2 : CK + 1; }
+static inline int conv_xpitch(int CK, int pixel_stride) {
+  if (const char* ev = RCV_ENV("RCV_XPITCH_PAD")) return CK + atoi(ev);      // experiments build only
+  return pixel_stride == 1 ? CK + 2 : CK + 1;
+}
 
 static inline void tile_halo(int kind, int R, int Wt, int s, int d, int* IH, int* IW) {
   if (kind == KIND_GATHER) { *IH = (R - 1) * s + 2 * d + 1; *IW = (Wt - 1) * s + 2 * d + 1; }
