@@ -506,6 +506,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
 
   // ---- input stream: registers -> (load transform) -> xl[g & 1] as [pixel][XK + pad]
   float4 px[XMAX], pa[AMAX];
+  float4 kx[5];                                  // load constants of this thread's quad for the chunk in px (requested with it)
   int xsrc[XMAX];                                // element offset of (pixel, quad) in the NHWC tensor, channel chunk 0; < 0: outside the plane
 #pragma unroll
   for (int u = 0; u < XMAX; ++u) {
@@ -524,20 +525,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
       if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
     }
   };
+  const int nkx = a.in_mode == RCV_LOAD_PLAIN ? 0 : ((a.in_mode == RCV_LOAD_AFFINE || a.in_mode == RCV_LOAD_AFFINE_RELU) ? 2 : (a.in_mode == RCV_LOAD_GRAD_ENC ? 3 : 5));
+  auto load_consts = [&](int g) {
+    // straight from the (L2-resident) constant rows, not through an LDS copy: an LDS read behind an outstanding LDS-DMA request
+    // makes the compiler wait for that request (possible alias), i.e. for the filter slab requested a tap earlier
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (j < nkx) kx[j] = ld4(a.in_c + j * a.Cin + g * XK + 4 * (tid & (XQ - 1)));
+  };
   auto load_x = [&](int g) {
 #pragma unroll
     for (int u = 0; u < XMAX; ++u) load_slot(g, u);
+    load_consts(g);
   };
   auto write_x_mode = [&](auto mode_c, int buf, int g) {
     constexpr int MODE = decltype(mode_c)::value;
     float* xb = xl + buf * a.xl_floats;
     const int q = tid & (XQ - 1);                // NT is a multiple of XQ: the quad of a thread is the same in every slot
     float4 k[5];
-    if (MODE != RCV_LOAD_PLAIN) {
-      constexpr int NK = (MODE == RCV_LOAD_AFFINE || MODE == RCV_LOAD_AFFINE_RELU) ? 2 : (MODE == RCV_LOAD_GRAD_ENC ? 3 : 5);
 #pragma unroll
-      for (int j = 0; j < NK; ++j) k[j] = *reinterpret_cast<const float4*>(cl + j * a.Cin + g * XK + 4 * q);
-    }
+    for (int j = 0; j < 5; ++j) k[j] = kx[j];
 #pragma unroll
     for (int u = 0; u < XMAX; ++u) {
       if (u * NT < xtotal) {
@@ -629,9 +636,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   // ---- prologue: F(0), X(0) and the load constants are requested together (one memory round trip)
   dma_w(0, 0);
   load_x(0);
-  if (a.in_c && a.in_mode != RCV_LOAD_PLAIN)
-    for (int e = tid; e < 5 * a.Cin; e += NT) cl[e] = a.in_c[e];
-  __syncthreads();
   write_x(0, 0);
   constexpr int JSPLIT = (KIND == KIND_GATHER || KIND == KIND_TALL) ? 5 : 2;
 #ifdef RCV_STAMPS
@@ -642,7 +646,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
     const int buf = i & 1;
     const int g = i / XSTEPS, sub = i - g * XSTEPS;
     // F(i) (and X(g+1), if this is the second step of the group) have landed: they were requested a whole step ago
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the builtin, not inline asm: the compiler's own wait insertion then KNOWS that the input registers requested a step ago have
+    // arrived, and does not park a vmcnt(0) in front of their use -- behind the LDS-DMA instructions issued in between)
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
     // xl[g & 1] complete, F(i) visible to every wave, buffers of step i-1 retired.  A bare barrier (the LDS writes of this wave are
     // waited for explicitly)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -698,6 +704,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
         if (SPREAD && j >= 5 && ldx) {                                           // X(g+1): registers, written to LDS in the next step
 #pragma unroll
           for (int q = 0; q < XMAX / 4; ++q) load_slot(g + 1, (j - 5) * (XMAX / 4) + q);
+          if (j == 8) load_consts(g + 1);
         }
         mfma_tap(cur, ph);
         ph = ph_next;
