@@ -197,6 +197,11 @@ int rcv_join_side(rcv_handle* h, void* stream);
  * milliseconds of op k to ms[k] (host memory). */
 int rcv_run_timed(rcv_handle* h, const rcv_op* ops, int n, void* stream, float* ms);
 
+/* Filter layout the library wants for an RCV_OP_CONV record before its filter is packed: 0 = [9 taps][Cin][Cout] (rcv_pack_job.merged
+ * 0), 2 = Winograd F(2x2,3x3) transformed [16][Cin][Cout] (rcv_pack_job.merged 2; the record then carries i[RCV_I_AUX0] = 2).  The
+ * wide stride-1 layers whose grid covers the chip answer 2; `force` != 0 answers 2 for every shape the Winograd kernel can run. */
+int rcv_op_filter_layout(const rcv_handle* h, const rcv_op* op, int force);
+
 /* Label of the kernel (template instantiation / tiling) the library launches for `op`, e.g.
  * "conv_mfma<2,5,4,1,8>" -- written NUL-terminated into buf[0..size). */
 int rcv_op_kernel_label(const rcv_handle* h, const rcv_op* op, char* buf, int size);
@@ -209,7 +214,8 @@ typedef struct rcv_pack_job {
   int32_t rows_from_d1;   /* 1: rows (contraction channel) = d1, cols = d0; 0: rows = d0, cols=d1 */
   int32_t flip;           /* 1: tap t reads source tap 8-t                                        */
   int32_t rows_pad, cols_pad;
-  int32_t merged;         /* 1: transposed-conv "merged parity" layout [4 taps (dy,dx)][rows][4*cols] (see conv_mfma.hip) */
+  int32_t merged;         /* 1: transposed-conv "merged parity" layout [4 taps (dy,dx)][rows][4*cols] (see conv_mfma.hip);
+                           * 2: Winograd layout [16][rows][cols] = G g G^T (see conv_wino.hip)                                  */
   int32_t reserved;
 } rcv_pack_job;
 

@@ -45,7 +45,7 @@ EXPORTS = [
     "rcv_run_timed", "rcv_op_kernel_label", "rcv_run_ex", "rcv_join_side",
     "rcv_conv3x3", "rcv_convT3x3s2", "rcv_wgrad3x3", "rcv_bn_finalize", "rcv_bn_backward", "rcv_maxpool2x2_fwd",
     "rcv_softmax_ce_argmax_fwd", "rcv_softmax_ce_bwd", "rcv_adam_l1_step", "rcv_adam_l1_step_metrics", "rcv_confusion",
-    "rcv_dice_fwd", "rcv_dice_bwd", "rcv_sgd_step", "rcv_create_planner", "rcv_adam_l1_step_pruned",
+    "rcv_dice_fwd", "rcv_dice_bwd", "rcv_sgd_step", "rcv_create_planner", "rcv_adam_l1_step_pruned", "rcv_op_filter_layout",
 ]
 
 
@@ -81,6 +81,7 @@ def load():
         lib.rcv_join_side.argtypes = [C.c_void_p, C.c_void_p]
         lib.rcv_run_timed.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_int, C.c_void_p, C.POINTER(C.c_float)]
         lib.rcv_op_kernel_label.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_char_p, C.c_int]
+        lib.rcv_op_filter_layout.argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_int]
         for name in ("rcv_conv3x3", "rcv_convT3x3s2", "rcv_wgrad3x3"):
             getattr(lib, name).argtypes = [C.c_void_p, C.POINTER(RcvOp), C.c_void_p]
         _lib = lib
@@ -137,6 +138,11 @@ def make_op(kind: int, flags: int = 0, **kw) -> RcvOp:
         else:
             op.i[globals()["RCV_I_" + k.upper()]] = int(v)
     return op
+
+
+def op_filter_layout(h, op: RcvOp, force: bool = False) -> int:
+    """0: plain [9][Cin][Cout] filter; 2: the library wants the Winograd-transformed filter for this conv record."""
+    return int(load().rcv_op_filter_layout(h, C.byref(op), 1 if force else 0))
 
 
 def op_workspace(h, op: RcvOp) -> int:

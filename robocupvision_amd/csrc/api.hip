@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include "rcv_internal.h"
+#include "conv_common.h"
 
 static thread_local char g_err[512] = "";
 
@@ -179,6 +180,11 @@ static int run_ops(rcv_handle* h, const rcv_op* ops, int n, void* stream, bool j
 }
 
 extern "C" {
+
+int rcv_op_filter_layout(const rcv_handle* h, const rcv_op* op, int force) {
+  if (!h || !op) return 0;
+  return conv_wino_wanted(h, op, force != 0) ? 2 : 0;
+}
 
 int rcv_op_kernel_label(const rcv_handle* h, const rcv_op* op, char* buf, int size) {
   RCV_CHECK_ARG(h && op && buf && size > 0, "rcv_op_kernel_label: bad arguments");

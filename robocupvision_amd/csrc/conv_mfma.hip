@@ -895,6 +895,9 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   pl->narrow = 0;
   pl->dma = 0;
   pl->first = 0;
+  pl->wino = 0;
+  if (conv_wino_supported(h, op, pl->kind)) return conv_wino_plan(h, op, pl);
+  RCV_CHECK_ARG(transposed || op->i[RCV_I_AUX0] != 2, "conv: a filter packed in the Winograd layout needs stride 1 / dilation 1");
   if (conv_first_supported(op, pl->kind)) return conv_first_plan(h, op, pl);
   if (convs_supported(h, op, pl->kind, CinP, pl->kind == KIND_TMERGED ? 4 * Cout : Cout)) return convs_make_plan(h, op, pl->kind, pl);
   pl->CK = (CinP % 8 == 0) ? 8 : 4;
@@ -1017,7 +1020,9 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   const int n_part = (pl.narrow || pl.first) ? pl.grid : n_pix_tiles * pl.n_phases;
   if (query) {
     static const char* kn[] = {"conv", "tconv", "tconvm", "tconva"};
-    if (pl.first) {
+    if (pl.wino) {
+      snprintf(query->label, sizeof(query->label), "conv_wino<64,80>");
+    } else if (pl.first) {
       snprintf(query->label, sizeof(query->label), "conv_first<%d>", op->i[RCV_I_DIL]);
     } else if (pl.narrow) {
       snprintf(query->label, sizeof(query->label), "%ss_mfma<%d,%d,%d>", kn[pl.kind], pl.WM, pl.WN, pl.CK);
@@ -1052,7 +1057,7 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   a.in_mode = op->i[RCV_I_INMODE]; a.stats = op->i[RCV_I_STATS]; a.flags = op->flags;
   a.wl_floats = pl.wl_floats; a.xl_floats = pl.xl_floats;
   a.xk = pl.xk;
-  a.xpitch = conv_xpitch(pl.dma ? pl.xk : pl.CK, pl.kind == KIND_GATHER ? a.stride : 1);
+  a.xpitch = conv_xpitch((pl.dma || pl.wino) ? pl.xk : pl.CK, pl.kind == KIND_GATHER ? a.stride : 1);
   a.fdWt = make_fastdiv(pl.Wt); a.fdIW = make_fastdiv(pl.IW);
 #ifdef RCV_STAMPS
   a.stamps = (unsigned long long*)op->p[RCV_P_X5];
@@ -1066,6 +1071,7 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   RCV_CHECK_ARG(a.stats == RCV_STATS_NONE || op->i[RCV_I_NPART] == n_part, "conv: workspace rows %d != %d", op->i[RCV_I_NPART], n_part);
   RCV_CHECK_ARG(!(a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC) || a.epi_aux, "conv: backward statistics need epi_aux");
   RCV_CHECK_ARG(!(a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC) || a.epi_c, "conv: backward statistics need epi_c (scale, shift, mean)");
+  if (pl.wino) return conv_wino_launch(pl, a, s);
   if (pl.first) return conv_first_launch(pl, a, s);
   if (pl.narrow) return convs_launch(pl, a, a.in_mode == RCV_LOAD_GRAD_ENC || a.in_mode == RCV_LOAD_GRAD_DEC, s);
   const dim3 grid(pl.grid);

@@ -24,6 +24,36 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 __global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
   const rcv_pack_job jb = jobs[blockIdx.y];
   const int per_tap = jb.rows_pad * jb.cols_pad;
+  if (jb.merged == 2) {
+    // Winograd F(2x2,3x3) filter transform U = G g G^T (conv_wino.hip): dst [16 xi = (a,b)][rows_pad][cols_pad],
+    //   G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
+    const int rows = jb.rows_from_d1 ? jb.D1 : jb.D0;
+    const int cols = jb.rows_from_d1 ? jb.D0 : jb.D1;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < per_tap; e += gridDim.x * blockDim.x) {
+      const int row = e / jb.cols_pad, col = e - row * jb.cols_pad;
+      float g[3][3];
+      const bool ok = row < rows && col < cols;
+      const int d0 = jb.rows_from_d1 ? col : row, d1 = jb.rows_from_d1 ? row : col;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = ok ? jb.src[((size_t)d0 * jb.D1 + d1) * 9 + (jb.flip ? 8 - t : t)] : 0.f;
+      float tg[4][3];      // G g
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        tg[0][q] = g[0][q];
+        tg[1][q] = 0.5f * (g[0][q] + g[1][q] + g[2][q]);
+        tg[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
+        tg[3][q] = g[2][q];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        jb.dst[(size_t)(a * 4 + 0) * per_tap + e] = tg[a][0];
+        jb.dst[(size_t)(a * 4 + 1) * per_tap + e] = 0.5f * (tg[a][0] + tg[a][1] + tg[a][2]);
+        jb.dst[(size_t)(a * 4 + 2) * per_tap + e] = 0.5f * (tg[a][0] - tg[a][1] + tg[a][2]);
+        jb.dst[(size_t)(a * 4 + 3) * per_tap + e] = tg[a][2];
+      }
+    }
+    return;
+  }
   const int total = (jb.merged ? 4 : 9) * per_tap;
   const int rows = jb.rows_from_d1 ? jb.D1 : jb.D0;
   const int cols = jb.rows_from_d1 ? jb.D0 : jb.D1;

@@ -36,6 +36,9 @@ SIDE_STREAM_MODE = os.environ.get("RCV_SIDE_STREAM", "auto")
 FUSE_UP_INTO_CLS = not os.environ.get("RCV_NO_FUSED_UP")
 CLS3_PAD = 8                    # class channels of the 3x3 classifier (v2) are padded to this many NHWC channels
 MERGED_TCONV_MAX_COUT = 16      # transposed convs with at most this many output channels use the merged-parity kernel
+# Winograd F(2x2,3x3) for the wide stride-1 convs (conv_wino.hip): "auto" = where the library asks for it (>= 64 channels and a grid that
+# covers the chip), "force" = wherever the kernel can run (tests), "off" = never
+WINOGRAD = os.environ.get("RCV_WINOGRAD", "auto")
 
 
 def _ptr(t: Optional[torch.Tensor]) -> int:
@@ -289,17 +292,24 @@ class Engine:
         # ---- weight packing table (all layers, one launch per forward) ----
         jobs: List[L.RcvPackJob] = []
 
-        def add_pack(param, D0, D1, rows_from_d1, flip, merged=False):
+        def add_pack(param, D0, D1, rows_from_d1, flip, merged=False, wino=False):
             rows = D1 if rows_from_d1 else D0
             cols = D0 if rows_from_d1 else D1
             rp, cp = _round_up(rows, 4), _round_up(cols * (4 if merged else 1), 16)
-            dst = self._zeros(plan, (4 if merged else 9) * rp * cp)
+            dst = self._zeros(plan, (16 if wino else (4 if merged else 9)) * rp * cp)
             j = L.RcvPackJob()
             j.src, j.dst, j.D0, j.D1 = param.data_ptr(), dst.data_ptr(), D0, D1
             j.rows_from_d1, j.flip, j.rows_pad, j.cols_pad = int(rows_from_d1), int(flip), rp, cp
-            j.merged = int(merged)
+            j.merged = 2 if wino else int(merged)
             jobs.append(j)
             return dst
+
+        def wants_winograd(op: L.RcvOp) -> bool:
+            """Ask the library whether this conv record should get the Winograd-transformed filter (and mark the record)."""
+            if WINOGRAD == "off" or not L.op_filter_layout(self.handle, op, WINOGRAD == "force"):
+                return False
+            op.i[L.RCV_I_AUX0] = 2
+            return True
 
         def use_merged(cout: int) -> bool:
             # narrow transposed convs are HBM bound: one pass writing whole output rows beats four parity passes
@@ -350,15 +360,16 @@ class Engine:
                 if Cin != src.C:
                     raise L.RcvError("conv node %d: input has %d channels, weight expects %d" % (node.idx, src.C, Cin))
                 Ho, Wo = (src.H - 1) // s + 1, (src.W - 1) // s + 1
-                node.t["wp"] = add_pack(w, Cout, Cin, True, False)
                 r = self._alloc(plan, N, Ho, Wo, Cout)
                 # order: 'relu_bn' = bn(relu(conv)) (Conv, model.py:115-116); 'bn_relu' = relu(bn(conv)) (ConvPoolSimple,
                 # model.py:175; the strided half of ConvPool, model.py:140-142); 'relu' = relu(conv), no BatchNorm (model.py:138-139)
                 order = _conv_order(d)
                 flags = (L.F_BIAS if b is not None else 0) | (L.F_RELU if order != "bn_relu" else 0)
                 op = L.make_op(L.OP_CONV, flags, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, ho=Ho, wo=Wo, stride=s, dil=dil,
-                               inmode=src.load_mode, p_in_c=_ptr(src.consts), p_w=node.t["wp"].data_ptr(),
+                               inmode=src.load_mode, p_in_c=_ptr(src.consts),
                                p_bias=_ptr(b), p_out=r.data_ptr())
+                node.t["wp"] = add_pack(w, Cout, Cin, True, False, wino=wants_winograd(op))
+                op.p[L.RCV_P_W] = node.t["wp"].data_ptr()
                 op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
                 if bn is not None:
                     bn_tensors(node, Cout)
@@ -666,10 +677,11 @@ class Engine:
                         bwd.append(L.make_op(L.OP_MEMSET, 0, count=b.numel(), p_out=fl.grad_ptr(b)))
                     if src.needs_grad:
                         if s == 1:
-                            node.t["wd"] = add_pack(w, Cout, Cin, False, True)
                             dop = L.make_op(L.OP_CONV, 0, n=N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=1, dil=dil,
                                             inmode=gmode, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
-                                            p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
+                                            p_in_c=node.t["bconsts"].data_ptr())
+                            node.t["wd"] = add_pack(w, Cout, Cin, False, True, wino=wants_winograd(dop))
+                            dop.p[L.RCV_P_W] = node.t["wd"].data_ptr()
                         else:
                             if src.H != 2 * out.H or src.W != 2 * out.W:
                                 raise L.RcvError("stride-2 conv backward needs even input dims (got %dx%d)" % (src.H, src.W))
@@ -703,7 +715,7 @@ class Engine:
             dev_table = host.to(self.device)
             plan.keep.append(dev_table)
             assert C.sizeof(table) == dev_table.numel()
-            max_elems = max((4 if j.merged else 9) * j.rows_pad * j.cols_pad for j in jobs)
+            max_elems = max((4 if j.merged == 1 else 9) * j.rows_pad * j.cols_pad for j in jobs)
             head = [L.make_op(L.OP_PACK, 0, count=len(jobs), aux0=max_elems, p_in=dev_table.data_ptr())] + head
         for slots in plan.input_slots:
             for i, (is_bwd, k, sl) in enumerate(slots):

@@ -5,6 +5,7 @@ FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE counts a wide (16 B/lane) coalesced 
 import collections, csv, glob, json, re, shutil, sys
 tag = sys.argv[1]
 base = "gpurun_out/prof_%s" % tag
+import os
 
 
 def kname(n):
@@ -34,5 +35,8 @@ json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate 
            "kernels": out}, open("profiles/%s_hbm_traffic.json" % tag, "w"), indent=1)
 shutil.copy(glob.glob(base + "/stats/runc/*_kernel_stats.csv")[0], "profiles/%s_kernel_stats.csv" % tag)
 shutil.copy(base + "/bench_stats.json", "profiles/%s_bench_under_rocprof.json" % tag)
+pmc = "gpurun_out/pmc_%s_conv128.txt" % tag
+if os.path.exists(pmc):
+    shutil.copy(pmc, "profiles/%s_conv_dma_128_sq_counters.txt" % tag)
 for k, v in list(out.items())[:8]:
     print("%-58s n=%3d %9.1f MB/launch" % (k[:58], v["launches"], v["hbm_bytes_per_launch"] / 1e6))

@@ -306,3 +306,64 @@ def test_adam_l1_named_entry_points_vs_torch():
     got = metrics.cpu().tolist()
     for a, b in zip(got, exp):
         assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (got, exp)
+
+
+def _abi_conv(x_nhwc, w, mode_wino, relu_bias=None):
+    """One RCV_OP_PACK + RCV_OP_CONV through the C ABI: plain 3x3 stride-1 conv of an NHWC tensor (no load transform)."""
+    from robocupvision_amd import _lib as L
+    import ctypes as C
+    dev = x_nhwc.device
+    h = L.handle(0)
+    N, H, W, Cin = x_nhwc.shape
+    Cout = w.shape[0]
+    rp, cp = (Cin + 3) // 4 * 4, (Cout + 15) // 16 * 16
+    wp = torch.zeros((16 if mode_wino else 9) * rp * cp, device=dev)
+    job = L.RcvPackJob()
+    job.src, job.dst, job.D0, job.D1 = w.data_ptr(), wp.data_ptr(), Cout, Cin
+    job.rows_from_d1, job.flip, job.rows_pad, job.cols_pad, job.merged = 1, 0, rp, cp, 2 if mode_wino else 0
+    table = torch.frombuffer(bytearray(bytes((L.RcvPackJob * 1)(job))), dtype=torch.uint8).to(dev)
+    out = torch.full((N, H, W, Cout), float("nan"), device=dev)
+    pack = L.make_op(L.OP_PACK, 0, count=1, aux0=16 * rp * cp, p_in=table.data_ptr())
+    conv = L.make_op(L.OP_CONV, 0, n=N, h=H, w=W, cin=Cin, cout=Cout, ho=H, wo=W, stride=1, dil=1, inmode=L.LOAD_PLAIN,
+                     aux0=2 if mode_wino else 0, p_in=x_nhwc.data_ptr(), p_w=wp.data_ptr(), p_out=out.data_ptr())
+    lst = L.OpList([pack, conv])
+    label = lst.labels(h)[1]
+    lst.run(h, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return out, label
+
+
+@pytest.mark.parametrize("N,H,W,C", [(4, 30, 40, 128), (2, 60, 80, 64), (3, 5, 7, 128), (1, 9, 3, 64), (2, 16, 34, 128)])
+def test_winograd_error_budget(N, H, W, C):
+    """fp32 error budget of the Winograd F(2x2,3x3) kernel (conv_wino.hip) on the layers it serves (the 128 -> 128 and 64 -> 64
+    stride-1 convs), against an fp64 convolution and against the direct MFMA kernel on the same data: the Winograd result must be
+    within 1e-5 of the output scale of the exact result (the parity bar for logits is 1e-3) and within 4x the direct kernel's own
+    error.  Ragged planes (odd sizes, one Winograd tile wide) included."""
+    g = torch.Generator().manual_seed(11)
+    x = (torch.relu(torch.randn(N, H, W, C, generator=g)) * 1.3 - 0.4)          # what a BatchNorm-of-ReLU activation looks like
+    w = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    xd, wd = x.to(DEV), w.to(DEV)
+    direct, ld = _abi_conv(xd, wd, False)
+    wino, lw = _abi_conv(xd, wd, True)
+    assert lw.startswith("conv_wino") and not ld.startswith("conv_wino"), (ld, lw)
+    scale = float(ref.abs().max())
+    e_d = float((direct.double().cpu() - ref).abs().max())
+    e_w = float((wino.double().cpu() - ref).abs().max())
+    print("winograd %s: scale %.3f, max error direct %.3e, winograd %.3e" % ((N, H, W, C), scale, e_d, e_w))
+    assert e_w <= 1e-5 * scale, (e_w, scale)
+    assert e_w <= 4 * e_d + 1e-7 * scale, (e_w, e_d)
+
+
+@pytest.mark.parametrize("name,c", [("conv_64_64_s1", 64), ("conv_128_128_s1", 128)])
+def test_conv_block_winograd(layer_kats, name, c, monkeypatch):
+    """The Conv block KATs of the wide layers with the Winograd kernel forced for forward AND data gradient (the reference's tiny,
+    odd planes: every tile ragged)."""
+    import robocupvision_amd.engine as E
+    monkeypatch.setattr(E, "WINOGRAD", "force")
+    mod = _load_block(layer_kats, name, M.Conv(c, c, 3, 1))
+    _run_block(layer_kats, name, mod)
+    eng = mod.__dict__["_engine"]
+    plan = [pl for (shape, training), pl in eng.plans.items() if training][0]
+    assert any(l.startswith("conv_wino") for l in plan.fwd.labels(eng.handle))
+    assert any(l.startswith("conv_wino") for l in plan.bwd.labels(eng.handle))

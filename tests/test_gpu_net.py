@@ -434,3 +434,35 @@ def test_trainer_fused_loss_is_bitwise_identical(net_kats):
     assert torch.equal(pa, pb) and torch.equal(aa, ab)
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+@pytest.mark.parametrize("tag", ["robo_l_1x48x64", "robo_s_2x48x64", "robo_l_2x480x640"])
+def test_step_vs_golden_winograd_forced(golden, tag, monkeypatch):
+    """The reference's golden steps with the Winograd kernel forced onto every layer it can run (all stride-1 convs with >= 64
+    channels, forward and data gradient): same bars as the direct path -- logits / loss 1e-3, arg-max mask exact outside the
+    reference's near-tie pixels, gradient norms 1e-3 (1e-2 on the cancellation-heavy per-channel sums)."""
+    import robocupvision_amd.engine as E
+    monkeypatch.setattr(E, "WINOGRAD", "force")
+    net_kats, m = golden(tag)
+    model = build(m["ctor"]).to(DEV)
+    if (tag + "/x") in net_kats.files:
+        x, t = _t(net_kats[tag + "/x"]), _t(net_kats[tag + "/t"])
+    else:
+        x, t = O.synthetic_batch(m["B"], m["H"], m["W"])
+    res = hip_step(model, x.to(DEV), t.to(DEV), do_step=False)
+    eng = model._get_engine()
+    plan = [pl for (shape, training), pl in eng.plans.items() if training][0]
+    nf = sum(l.startswith("conv_wino") for l in plan.fwd.labels(eng.handle))
+    nb = sum(l.startswith("conv_wino") for l in plan.bwd.labels(eng.handle))
+    assert nf >= 6 and nb >= 5, (nf, nb)
+    assert abs(res["ce"] - m["ce"]) <= 1e-3 * abs(m["ce"]), (res["ce"], m["ce"])
+    las = float(res["pred"].double().abs().sum())
+    assert abs(las - m["logits_abs_sum"]) <= 1e-3 * m["logits_abs_sum"]
+    check_mask(res["pc"], net_kats[tag + "/argmax"], net_kats[tag + "/near_tie_idx"], tag + " (winograd)")
+    for k, g in res["grads"].items():
+        if k.startswith("upPart") and k.endswith("conv.bias"):
+            continue
+        n32, n64 = m["grad_summary"][k][2], m["fp64"]["grad_summary"][k][2]
+        got = float(g.double().norm())
+        tol = 1e-2 if (k.endswith("bn.weight") or k.endswith("bn.bias") or k.endswith("conv.bias")) else 1e-3
+        assert abs(got - n32) <= tol * n32 + 1e-7 or abs(got - n64) <= tol * n64 + 1e-7, (k, got, n32, n64)

@@ -1,6 +1,8 @@
 """CPU: the oracle (oracle/cpu_reference.py) against golden vectors produced by the imported reference
 (tests/golden/make_golden.py).  Bit-for-bit at 8 threads, the thread count the goldens were made at
 (the reference's own CPU output moves by ~1e-6 across thread counts)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -170,3 +172,47 @@ def test_conv_macs_match_survey():
     s = O.conv_macs(O.NetConfig(), 120, 160)[0]
     l = O.conv_macs(O.NetConfig(noScale=True), 480, 640)[0]
     assert abs(2 * s / 1e9 - 0.4964) < 5e-4 and abs(2 * l / 1e9 - 4.7579) < 5e-4
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/pth/bestModelLP.pth"), reason="build container only: the reference and its trained weights do not travel")
+def test_labelprop_oracle_vs_reference_on_shipped_weights():
+    """the oracle's LabelProp restatement against the IMPORTED reference (model.py:538-567) with the reference's own
+    trained weights (pth/bestModelLP.pth, loaded with weights_only=True: nothing from the file is executed), eval mode, on a
+    frame-pair input built with the labelPropTrain.py:178-182 recipe.  Bit-identical logits.  The reference class cannot be
+    constructed at HEAD (8 arguments passed to the 7-argument ConvPoolSimple.__init__): the constructor is wrapped to
+    drop the extra (dropout) argument, exactly as tests/golden/make_golden.py does; the arithmetic is untouched."""
+    import sys
+    import torch
+    from oracle import cpu_reference as O
+    sys.path.insert(0, "/root/reference")
+    try:
+        import model as ref
+    finally:
+        sys.path.remove("/root/reference")
+    orig = ref.ConvPoolSimple.__init__
+
+    def patched(self, inplanes, planes, size, stride, padding, dilation, bias, *_ignored):
+        orig(self, inplanes, planes, size, stride, padding, dilation, bias)
+    ref.ConvPoolSimple.__init__ = patched
+    try:
+        net = ref.LabelProp(5, 32, 0.0)
+    finally:
+        ref.ConvPoolSimple.__init__ = orig
+    sd = torch.load("/root/reference/pth/bestModelLP.pth", map_location="cpu", weights_only=True)
+    missing, unexpected = net.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    net.eval()
+    g = torch.Generator().manual_seed(5)
+    y_t = torch.randn(120, 160, generator=g)
+    y_n = y_t + 0.1 * torch.randn(120, 160, generator=g)
+    x = O.labelprop_inputs(y_t, y_n, torch.randint(0, 5, (120, 160), generator=g), torch.randint(0, 5, (120, 160), generator=g))
+    old = torch.get_num_threads()
+    torch.set_num_threads(8)
+    try:
+        with torch.no_grad():
+            want = net(x.clone())
+            got = O.labelprop_forward({k: v.clone() for k, v in sd.items()}, x.clone())
+    finally:
+        torch.set_num_threads(old)
+    assert torch.equal(got, want)
+    assert len(sd) == 55 and sum(v.numel() for v in sd.values()) == 92837      # SURVEY 8(c): 55 keys / 92 837 elements
