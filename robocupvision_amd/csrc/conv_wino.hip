@@ -37,6 +37,7 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
   float* ul = smem;                                // [2][W_UBUF]
   float* vl = ul + 2 * W_UBUF;                     // [2][W_VBUF]
   float* xl = vl + 2 * W_VBUF;                     // [2][xl_floats]: raw (load-transformed) input chunk, [pixel][16 + 2]
+  float* cl = xl + 2 * a.xl_floats;                // [5][Cin] load constants (in LDS, not registers: the accumulators leave no room)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
   };
 
   // ---- raw input chunk: registers -> (load transform) -> xl
-  float4 px[W_XMAX], pa[TWO ? W_XMAX : 1], kx[5];
+  float4 px[W_XMAX], pa[TWO ? W_XMAX : 1];
   int xsrc[W_XMAX];
 #pragma unroll
   for (int u = 0; u < W_XMAX; ++u) {
@@ -85,7 +86,6 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
     const bool ok = idx < xtotal && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     xsrc[u] = ok ? (((n * a.H + gy) * a.W + gx) * a.Cin + 4 * q) : -1;
   }
-  const int nkx = a.in_mode == RCV_LOAD_PLAIN ? 0 : ((a.in_mode == RCV_LOAD_AFFINE || a.in_mode == RCV_LOAD_AFFINE_RELU) ? 2 : (a.in_mode == RCV_LOAD_GRAD_ENC ? 3 : 5));
   auto load_x = [&](int g) {
 #pragma unroll
     for (int u = 0; u < W_XMAX; ++u) {
@@ -95,14 +95,17 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
         if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
       }
     }
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-      if (j < nkx) kx[j] = ld4(a.in_c + j * a.Cin + g * W_XK + 4 * (tid & 3));
   };
-  auto write_x_mode = [&](auto mode_c, int buf) {
+  auto write_x_mode = [&](auto mode_c, int buf, int g) {
     constexpr int MODE = decltype(mode_c)::value;
     float* xb = xl + buf * a.xl_floats;
     const int q = tid & 3;
+    float4 kx[5];
+    if (MODE != RCV_LOAD_PLAIN) {
+      constexpr int NK = (MODE == RCV_LOAD_AFFINE || MODE == RCV_LOAD_AFFINE_RELU) ? 2 : (MODE == RCV_LOAD_GRAD_ENC ? 3 : 5);
+#pragma unroll
+      for (int j = 0; j < NK; ++j) kx[j] = *reinterpret_cast<const float4*>(cl + j * a.Cin + g * W_XK + 4 * q);
+    }
 #pragma unroll
     for (int u = 0; u < W_XMAX; ++u) {
       if (u * W_NT < xtotal) {
@@ -116,14 +119,14 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
       }
     }
   };
-  auto write_x = [&](int buf) {
+  auto write_x = [&](int buf, int g) {
     if constexpr (TWO) {
-      if (a.in_mode == RCV_LOAD_GRAD_ENC) write_x_mode(std::integral_constant<int, RCV_LOAD_GRAD_ENC>{}, buf);
-      else write_x_mode(std::integral_constant<int, RCV_LOAD_GRAD_DEC>{}, buf);
+      if (a.in_mode == RCV_LOAD_GRAD_ENC) write_x_mode(std::integral_constant<int, RCV_LOAD_GRAD_ENC>{}, buf, g);
+      else write_x_mode(std::integral_constant<int, RCV_LOAD_GRAD_DEC>{}, buf, g);
     } else {
-      if (a.in_mode == RCV_LOAD_AFFINE) write_x_mode(std::integral_constant<int, RCV_LOAD_AFFINE>{}, buf);
-      else if (a.in_mode == RCV_LOAD_AFFINE_RELU) write_x_mode(std::integral_constant<int, RCV_LOAD_AFFINE_RELU>{}, buf);
-      else write_x_mode(std::integral_constant<int, RCV_LOAD_PLAIN>{}, buf);
+      if (a.in_mode == RCV_LOAD_AFFINE) write_x_mode(std::integral_constant<int, RCV_LOAD_AFFINE>{}, buf, g);
+      else if (a.in_mode == RCV_LOAD_AFFINE_RELU) write_x_mode(std::integral_constant<int, RCV_LOAD_AFFINE_RELU>{}, buf, g);
+      else write_x_mode(std::integral_constant<int, RCV_LOAD_PLAIN>{}, buf, g);
     }
   };
 
@@ -180,7 +183,10 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
   // ---- prologue
   dma_u(0, 0);
   load_x(0);
-  write_x(0);
+  if (a.in_c && a.in_mode != RCV_LOAD_PLAIN)
+    for (int e = tid; e < 5 * a.Cin; e += W_NT) cl[e] = a.in_c[e];
+  __syncthreads();
+  write_x(0, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   v_transform(0, xl);
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
         v_transform(buf ^ 1, xl + (g1 & 1) * a.xl_floats + sub1 * W_CK);
       }
     }
-    if (sub == 1 && g + 1 < ngroups) write_x((g + 1) & 1);     // X(g+1) -> LDS; first read by the V transform two k-steps later
+    if (sub == 1 && g + 1 < ngroups) write_x((g + 1) & 1, g + 1);     // X(g+1) -> LDS; first read by the V transform two k-steps later
   }
 
   // ---- output transform + epilogue, one 16-tile block at a time through LDS
@@ -386,7 +392,7 @@ int conv_wino_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   pl->xk = W_XK;
   pl->xl_floats = round_up(pl->IH * pl->IW * conv_xpitch(W_XK, 1), 4);
   pl->wl_floats = 0;
-  size_t floats = 2 * (size_t)W_UBUF + 2 * (size_t)W_VBUF + 2 * (size_t)pl->xl_floats;
+  size_t floats = 2 * (size_t)W_UBUF + 2 * (size_t)W_VBUF + 2 * (size_t)pl->xl_floats + 5 * (size_t)round_up(Cin, 4);
   const size_t exch = (size_t)16 * 16 * W_EXP;
   if (floats < exch) floats = exch;
   pl->lds = floats * sizeof(float);
