@@ -242,34 +242,13 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
   const bool bwd_stats = a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC;
 #pragma unroll
   for (int tb = 0; tb < W_TB; ++tb) {
-    __syncthreads();                                 // the K loop / the previous block is done with this LDS
-#pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      const int xi = 2 * wave + x;
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        *reinterpret_cast<float4*>(ex + (xi * 16 + l15) * W_EXP + m * 16 + 4 * l4) =
-            make_float4(acc[x][m][tb][0], acc[x][m][tb][1], acc[x][m][tb][2], acc[x][m][tb][3]);
-    }
-    __syncthreads();
+    // this thread's two output pixels of the block, and their skip-gradient / BatchNorm-backward operands: requested BEFORE the
+    // exchange, so that their HBM round trip runs under the two barriers and the LDS traffic of the block
     const int q = tb * 16 + e_tile;
     const int tr = fd_div(q < ntile ? q : 0, a.fdWt), tc = (q < ntile ? q : 0) - tr * a.Wt;
     const int oy = 2 * (ty0 + tr) + e_i;
     const int oxb = 2 * (tx0 + tc);
     const bool row_ok = q < ntile && co_ok && oy < a.Ho;
-    // rows a of M needed for output row i: i = 0: a = 0,1,2 (+ + +); i = 1: a = 1,2,3 (+ - -)
-    float4 rs[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const float4 m1 = *reinterpret_cast<const float4*>(ex + ((1 * 4 + b) * 16 + e_tile) * W_EXP + 4 * e_quad);
-      const float4 m2 = *reinterpret_cast<const float4*>(ex + ((2 * 4 + b) * 16 + e_tile) * W_EXP + 4 * e_quad);
-      const float4 m03 = *reinterpret_cast<const float4*>(ex + (((e_i ? 3 : 0) * 4 + b) * 16 + e_tile) * W_EXP + 4 * e_quad);
-      if (e_i == 0) rs[b] = make_float4(m03.x + m1.x + m2.x, m03.y + m1.y + m2.y, m03.z + m1.z + m2.z, m03.w + m1.w + m2.w);
-      else rs[b] = make_float4(m1.x - m2.x - m03.x, m1.y - m2.y - m03.y, m1.z - m2.z - m03.z, m1.w - m2.w - m03.w);
-    }
-    float4 o[2];
-    o[0] = make_float4(rs[0].x + rs[1].x + rs[2].x, rs[0].y + rs[1].y + rs[2].y, rs[0].z + rs[1].z + rs[2].z, rs[0].w + rs[1].w + rs[2].w);
-    o[1] = make_float4(rs[1].x - rs[2].x - rs[3].x, rs[1].y - rs[2].y - rs[3].y, rs[1].z - rs[2].z - rs[3].z, rs[1].w - rs[2].w - rs[3].w);
     bool okp[2];
     size_t offp[2];
     float4 rr[2], ee[2];
@@ -287,6 +266,29 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
 #pragma unroll
       for (int jx = 0; jx < 2; ++jx) ee[jx] = ld4(a.epi_aux + offp[jx]);
     }
+    __syncthreads();                                 // the K loop / the previous block is done with this LDS
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const int xi = 2 * wave + x;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        *reinterpret_cast<float4*>(ex + (xi * 16 + l15) * W_EXP + m * 16 + 4 * l4) =
+            make_float4(acc[x][m][tb][0], acc[x][m][tb][1], acc[x][m][tb][2], acc[x][m][tb][3]);
+    }
+    __syncthreads();
+    // rows a of M needed for output row i: i = 0: a = 0,1,2 (+ + +); i = 1: a = 1,2,3 (+ - -)
+    float4 rs[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float4 m1 = *reinterpret_cast<const float4*>(ex + ((1 * 4 + b) * 16 + e_tile) * W_EXP + 4 * e_quad);
+      const float4 m2 = *reinterpret_cast<const float4*>(ex + ((2 * 4 + b) * 16 + e_tile) * W_EXP + 4 * e_quad);
+      const float4 m03 = *reinterpret_cast<const float4*>(ex + (((e_i ? 3 : 0) * 4 + b) * 16 + e_tile) * W_EXP + 4 * e_quad);
+      if (e_i == 0) rs[b] = make_float4(m03.x + m1.x + m2.x, m03.y + m1.y + m2.y, m03.z + m1.z + m2.z, m03.w + m1.w + m2.w);
+      else rs[b] = make_float4(m1.x - m2.x - m03.x, m1.y - m2.y - m03.y, m1.z - m2.z - m03.z, m1.w - m2.w - m03.w);
+    }
+    float4 o[2];
+    o[0] = make_float4(rs[0].x + rs[1].x + rs[2].x, rs[0].y + rs[1].y + rs[2].y, rs[0].z + rs[1].z + rs[2].z, rs[0].w + rs[1].w + rs[2].w);
+    o[1] = make_float4(rs[1].x - rs[2].x - rs[3].x, rs[1].y - rs[2].y - rs[3].y, rs[1].z - rs[2].z - rs[3].z, rs[1].w - rs[2].w - rs[3].w);
 #pragma unroll
     for (int jx = 0; jx < 2; ++jx) {
       if (!okp[jx]) continue;
