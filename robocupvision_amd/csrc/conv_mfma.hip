@@ -1021,7 +1021,7 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   if (query) {
     static const char* kn[] = {"conv", "tconv", "tconvm", "tconva"};
     if (pl.wino) {
-      snprintf(query->label, sizeof(query->label), "conv_wino<64,80>");
+      snprintf(query->label, sizeof(query->label), "conv_wino<64,%d>", 16 * pl.WN);
     } else if (pl.first) {
       snprintf(query->label, sizeof(query->label), "conv_first<%d>", op->i[RCV_I_DIL]);
     } else if (pl.narrow) {

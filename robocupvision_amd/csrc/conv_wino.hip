@@ -24,15 +24,16 @@ typedef __attribute__((address_space(3))) void* wino_lds_ptr;
 typedef const __attribute__((address_space(1))) void* wino_glb_ptr;
 
 namespace {
-constexpr int W_NT = 512, W_NW = 8, W_COT = 64, W_TILES = 80, W_TB = 5, W_CK = 4, W_XK = 16, W_XMAX = 4;
+constexpr int W_NT = 512, W_NW = 8, W_COT = 64, W_CK = 4, W_XK = 16, W_XMAX = 4;
 constexpr int W_UBUF = 16 * W_CK * W_COT;          // floats of one U k-step slab
-constexpr int W_VP = 80;                           // row pitch of V ([xi][ci][tile]); 80 = 16 mod 32: the two k-lanes of a 32-lane group hit different banks
-constexpr int W_VBUF = 16 * W_CK * W_VP;
+// W_TB = 16-tile blocks of a workgroup: 5 (80 tiles, the large planes) or 3 (48 tiles: planes whose 80-tile grid would leave CUs idle).
+// Row pitch of V ([xi][ci][tile]) = 16 W_TB = 16 mod 32 for both: the two k-lanes of a 32-lane LDS access group hit different banks.
 constexpr int W_EXP = W_COT + 4;                   // pitch of the exchange image [xi][tile][co] (68: conflict-free 16-byte accesses)
 }
 
-template <bool TWO>
+template <bool TWO, int W_TB>
 __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
+  constexpr int W_TILES = 16 * W_TB, W_VP = W_TILES, W_VBUF = 16 * W_CK * W_VP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* ul = smem;                                // [2][W_UBUF]
   float* vl = ul + 2 * W_UBUF;                     // [2][W_VBUF]
@@ -371,21 +372,33 @@ int conv_wino_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   RCV_CHECK_ARG(op->i[RCV_I_STRIDE] == 1 && op->i[RCV_I_DIL] == 1 && Cin % 16 == 0 && Cout % 4 == 0,
                 "winograd conv: needs stride 1, dilation 1, Cin %% 16 == 0 (got s%d d%d Cin %d Cout %d)", op->i[RCV_I_STRIDE], op->i[RCV_I_DIL], Cin, Cout);
   const int TH = ceil_div(Ho, 2), TW = ceil_div(Wo, 2);       // Winograd tiles of a plane
-  // tile block: widest row segment of tiles, then as many tile rows as fit in 80 tiles and 512 staged pixels
-  int best = -1, bR = 0, bW = 0;
-  for (int nx = 1; nx <= TW; ++nx) {
-    const int wt = ceil_div(TW, nx);
-    if (wt > W_TILES) continue;
-    int r = W_TILES / wt;
-    if (r > TH) r = TH;
-    while (r >= 1 && (2 * r + 2) * (2 * wt + 2) > 512) --r;
-    if (r < 1) continue;
-    r = ceil_div(TH, ceil_div(TH, r));
-    const int blocks = ceil_div(TW, wt) * ceil_div(TH, r);
-    if (best < 0 || blocks < best) { best = blocks; bR = r; bW = wt; }
-    if (wt < 8) break;
-  }
+  // tile block: widest row segment of tiles, then as many tile rows as fit in the workgroup's tiles and 512 staged pixels
+  auto plan_blocks = [&](int tiles, int* bR, int* bW) {
+    int best = -1;
+    for (int nx = 1; nx <= TW; ++nx) {
+      const int wt = ceil_div(TW, nx);
+      if (wt > tiles) continue;
+      int r = tiles / wt;
+      if (r > TH) r = TH;
+      while (r >= 1 && (2 * r + 2) * (2 * wt + 2) > 512) --r;
+      if (r < 1) continue;
+      r = ceil_div(TH, ceil_div(TH, r));
+      const int blocks = ceil_div(TW, wt) * ceil_div(TH, r);
+      if (best < 0 || blocks < best) { best = blocks; *bR = r; *bW = wt; }
+      if (wt < 8) break;
+    }
+    return best;
+  };
+  int bR = 0, bW = 0;
+  int best = plan_blocks(80, &bR, &bW);
   RCV_CHECK_ARG(best > 0, "winograd conv: no tile block for a %dx%d plane", Ho, Wo);
+  pl->WN = 5;                                                // 16-tile blocks per workgroup
+  const int n_co = ceil_div(round_up(Cout, 16), W_COT);
+  if ((long)N * best * n_co * 4 < (long)h->num_cus * 3) {    // the 80-tile grid leaves CUs idle: 48-tile workgroups if THEY cover the chip
+    int r3 = 0, w3 = 0;
+    const int b3 = plan_blocks(48, &r3, &w3);
+    if (b3 > 0 && (long)N * b3 * n_co * 4 >= (long)h->num_cus * 3) { best = b3; bR = r3; bW = w3; pl->WN = 3; }
+  }
   pl->kind = KIND_GATHER; pl->tile = 0; pl->CK = 4; pl->narrow = 0; pl->dma = 0; pl->first = 0; pl->wino = 1;
   pl->R = bR; pl->Wt = bW; pl->tiles_x = ceil_div(TW, bW); pl->tiles_y = ceil_div(TH, bR);
   pl->IH = 2 * bR + 2; pl->IW = 2 * bW + 2;
@@ -394,7 +407,7 @@ int conv_wino_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   pl->xk = W_XK;
   pl->xl_floats = round_up(pl->IH * pl->IW * conv_xpitch(W_XK, 1), 4);
   pl->wl_floats = 0;
-  size_t floats = 2 * (size_t)W_UBUF + 2 * (size_t)W_VBUF + 2 * (size_t)pl->xl_floats + 5 * (size_t)round_up(Cin, 4);
+  size_t floats = 2 * (size_t)W_UBUF + 2 * (size_t)(16 * W_CK * 16 * pl->WN) + 2 * (size_t)pl->xl_floats + 5 * (size_t)round_up(Cin, 4);
   const size_t exch = (size_t)16 * 16 * W_EXP;
   if (floats < exch) floats = exch;
   pl->lds = floats * sizeof(float);
@@ -406,17 +419,16 @@ int conv_wino_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
 
 int conv_wino_launch(const ConvPlan& pl, const ConvArgs& a, hipStream_t s) {
   const bool two = a.in_mode == RCV_LOAD_GRAD_ENC || a.in_mode == RCV_LOAD_GRAD_DEC;
-  if (two) {
-    auto kern = conv_wino_kernel<true>;
-    static size_t configured[RCV_MAX_DEVICES];
-    RCV_ENSURE_LDS(kern, pl.lds, pl.dev, configured);
-    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(W_NT), pl.lds, s, a);
-  } else {
-    auto kern = conv_wino_kernel<false>;
-    static size_t configured[RCV_MAX_DEVICES];
-    RCV_ENSURE_LDS(kern, pl.lds, pl.dev, configured);
-    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(W_NT), pl.lds, s, a);
-  }
+#define WINO_LAUNCH(TWO_, TB_)                                                         \
+  do {                                                                                 \
+    auto kern = conv_wino_kernel<TWO_, TB_>;                                           \
+    static size_t configured[RCV_MAX_DEVICES];                                         \
+    RCV_ENSURE_LDS(kern, pl.lds, pl.dev, configured);                                  \
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(W_NT), pl.lds, s, a);                 \
+  } while (0)
+  if (pl.WN == 3) { if (two) WINO_LAUNCH(true, 3); else WINO_LAUNCH(false, 3); }
+  else { if (two) WINO_LAUNCH(true, 5); else WINO_LAUNCH(false, 5); }
+#undef WINO_LAUNCH
   RCV_HIP(hipGetLastError());
   return RCV_OK;
 }
