@@ -23,6 +23,54 @@
 #include <stdlib.h>
 #include "wgrad_common.h"
 
+// One operand tile, global -> (load transform) -> LDS.  Tile-local pixel `pix` = (iy, ix) with ix < TW; it is real when ix < TWV and
+// (oy + iy, ox + ix) lies inside the PH x PW plane of image row block `row0` (= n * PH); everything else is stored as zero.  Q
+// threads share a pixel (one 16-byte channel quad each), UNR independent loads per thread in flight.  Offsets are 32-bit from the
+// tensor base (checked on the host: fewer than 2^31 elements) and the loads are unconditional (lanes without a real pixel read
+// element 0 and discard it), so that the loop body is straight-line code for every load mode.
+template <int MODE, int UNR, bool SUM, bool SCALAR_STORE>
+__device__ __forceinline__ void wstage_tile(const float* __restrict__ src, const float* __restrict__ aux, const float* __restrict__ consts,
+                                            float* __restrict__ lds, int tid, int nthreads, int Q, int ch0, int C, int npix, FastDiv fdTW, int TW,
+                                            int TWV, int row0, int oy, int ox, int PH, int PW, int S, float4& sum) {
+  constexpr bool TWO = MODE == RCV_LOAD_GRAD_ENC || MODE == RCV_LOAD_GRAD_DEC;
+  const int q = tid % Q;
+  const int ch = ch0 + 4 * q;
+  const bool ch_ok = ch < C;
+  float4 k[5];
+  if (MODE != RCV_LOAD_PLAIN) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) k[j] = ch_ok ? wld4(consts + (size_t)j * C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int step = nthreads / Q;
+  for (int pix0 = tid / Q; pix0 < npix; pix0 += UNR * step) {
+    float4 x[UNR], ax[UNR];
+    bool ok[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int pix = pix0 + u * step;
+      const int iy = fd_div(pix, fdTW), ix = pix - iy * TW;
+      const int gy = oy + iy, gx = ox + ix;
+      ok[u] = ch_ok && pix < npix && ix < TWV && (unsigned)gy < (unsigned)PH && (unsigned)gx < (unsigned)PW;
+      const int off = ok[u] ? ((row0 + gy) * PW + gx) * C + ch : 0;
+      x[u] = wld4(src + off);
+      if (TWO) ax[u] = wld4(aux + off);
+      else ax[u] = x[u];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int pix = pix0 + u * step;
+      float4 v = wxform4<MODE>(x[u], ax[u], k);
+      if (!ok[u]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (SUM) { sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w; }
+      if (pix < npix) {
+        float* dst = lds + pix * S + 4 * q;
+        if (SCALAR_STORE) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+        else *reinterpret_cast<float4*>(dst) = v;
+      }
+    }
+  }
+}
+
 // NBF == 0: regular mode (WN column blocks of 16 gathered channels, 9 taps each)
 // NBF  > 0: folded mode (WN must be 1): NBF column blocks over n = tap*CA + ca
 // GTWO: the gathered operand is a two-tensor gradient load (convT layer); otherwise the pointwise one may be.
@@ -59,16 +107,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
   // channels in a 16-wide tile only half the staging threads would otherwise have a load to issue
   int QP = QPMAX;
   while (QP > 1 && (QP / 2) * 4 >= a.CB - cb0) QP /= 2;
-  const int STEPP = NT / QP;
   const int s = a.stride, d = a.dil;
   const int QG = FOLD ? (a.CA + 3) / 4 : CAT / 4;        // 16-byte quads per staged gathered pixel
-  const int STEPG = NT / QG;
   const int np_pix = a.R * a.Wt4, ng_pix = a.IH * a.IW;
 
 
   // ---------------- staging: global -> (load transform) -> LDS, 4 independent 16-byte loads per thread in flight ----------------
-  const bool p_two = a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC;
-  const bool g_two = a.g_mode == RCV_LOAD_GRAD_ENC || a.g_mode == RCV_LOAD_GRAD_DEC;
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int UNR = (FOLD || (SPEC && WAVES_K != 2)) ? 8 : 4;     // folded (<= 8 channel) tiles are HBM bound: more loads in flight (8 on the 16 x 16 tile: measured, no gain; on the 32 x 16 tiles > 256 registers)
   auto stage = [&](int tile, float* pl, float* gl) {
@@ -78,45 +122,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
     const int ty_i = t % a.tiles_y;
     const int n = t / a.tiles_y;
     const int y0 = ty_i * a.R, x0 = tx_i * a.Wt;
-    {   // pointwise tile: R x Wt4 pixels (columns >= Wt and anything outside the plane are zero)
-      const int q = tid % QP;
-      const int ch = cb0 + 4 * q;
-      const bool ch_ok = ch < a.CB;
-      float4 k[5];
-      if (a.p_mode != RCV_LOAD_PLAIN && ch_ok) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) k[j] = wld4(a.p_c + (size_t)j * a.CB + ch);
-      }
-      for (int pix0 = tid / QP; pix0 < np_pix; pix0 += UNR * STEPP) {
-        float4 x[UNR], ax[UNR];
-        bool ok[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int pix = pix0 + u * STEPP;
-          const int iy = fd_div(pix, a.fdWt4), ix = pix - iy * a.Wt4;
-          const int gy = y0 + iy, gx = x0 + ix;
-          ok[u] = pix < np_pix && ch_ok && ix < a.Wt && gy < a.Hp && gx < a.Wp;
-          x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          ax[u] = x[u];
-          if (ok[u]) {
-            const size_t off = ((size_t)(n * a.Hp + gy) * a.Wp + gx) * a.CB + ch;
-            x[u] = wld4(a.p + off);
-            if (p_two) ax[u] = wld4(a.p_aux + off);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int pix = pix0 + u * STEPP;
-          if (pix < np_pix) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok[u]) {
-              v = wxform_rt(a.p_mode, x[u], ax[u], k);
-              bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
-            }
-            *reinterpret_cast<float4*>(pl + pix * a.SP + 4 * q) = v;
-          }
-        }
-      }
+    // pointwise tile: R x Wt4 pixels (columns >= Wt and anything outside the plane are zero)
+    // (GTWO: the host guarantees that at most one operand is a two-tensor gradient load -- the other switch arms are never compiled)
+    switch (GTWO && (a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC) ? RCV_LOAD_PLAIN : a.p_mode) {
+      case RCV_LOAD_PLAIN: wstage_tile<RCV_LOAD_PLAIN, UNR, true, false>(a.p, a.p_aux, a.p_c, pl, tid, NT, QP, cb0, a.CB, np_pix, a.fdWt4, a.Wt4, a.Wt, n * a.Hp, y0, x0, a.Hp, a.Wp, a.SP, bsum); break;
+      case RCV_LOAD_AFFINE: wstage_tile<RCV_LOAD_AFFINE, UNR, true, false>(a.p, a.p_aux, a.p_c, pl, tid, NT, QP, cb0, a.CB, np_pix, a.fdWt4, a.Wt4, a.Wt, n * a.Hp, y0, x0, a.Hp, a.Wp, a.SP, bsum); break;
+      case RCV_LOAD_AFFINE_RELU: wstage_tile<RCV_LOAD_AFFINE_RELU, UNR, true, false>(a.p, a.p_aux, a.p_c, pl, tid, NT, QP, cb0, a.CB, np_pix, a.fdWt4, a.Wt4, a.Wt, n * a.Hp, y0, x0, a.Hp, a.Wp, a.SP, bsum); break;
+      case RCV_LOAD_GRAD_ENC: if (!GTWO) wstage_tile<RCV_LOAD_GRAD_ENC, UNR, true, false>(a.p, a.p_aux, a.p_c, pl, tid, NT, QP, cb0, a.CB, np_pix, a.fdWt4, a.Wt4, a.Wt, n * a.Hp, y0, x0, a.Hp, a.Wp, a.SP, bsum); break;
+      default: if (!GTWO) wstage_tile<RCV_LOAD_GRAD_DEC, UNR, true, false>(a.p, a.p_aux, a.p_c, pl, tid, NT, QP, cb0, a.CB, np_pix, a.fdWt4, a.Wt4, a.Wt, n * a.Hp, y0, x0, a.Hp, a.Wp, a.SP, bsum); break;
     }
     if (a.g_mode == RCV_LOAD_NCHW) {   // gathered tile from the NCHW image: one pixel (<= 4 planes) per thread
       for (int pix0 = tid; pix0 < ng_pix; pix0 += UNR * NT) {
@@ -150,41 +163,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
         }
       }
     } else {
-      const int q = tid % QG;
-      const int ch = ca0 + 4 * q;
-      const bool ch_ok = ch < a.CA;
-      float4 k[5];
-      if (a.g_mode != RCV_LOAD_PLAIN && ch_ok) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) k[j] = wld4(a.g_c + (size_t)j * a.CA + ch);
-      }
-      for (int pix0 = tid / QG; pix0 < ng_pix; pix0 += UNR * STEPG) {
-        float4 x[UNR], ax[UNR];
-        bool ok[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int pix = pix0 + u * STEPG;
-          const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
-          const int gy = y0 * s - d + iy, gx = x0 * s - d + ix;
-          ok[u] = pix < ng_pix && ch_ok && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-          x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          ax[u] = x[u];
-          if (ok[u]) {
-            const size_t off = ((size_t)(n * a.H + gy) * a.W + gx) * a.CA + ch;
-            x[u] = wld4(a.g + off);
-            if (g_two) ax[u] = wld4(a.g_aux + off);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-          const int pix = pix0 + u * STEPG;
-          if (pix < ng_pix) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok[u]) v = wxform_rt(a.g_mode, x[u], ax[u], k);
-            float* dst = gl + pix * a.SG + 4 * q;
-            if (FOLD) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
-            else *reinterpret_cast<float4*>(dst) = v;
-          }
+      // gathered tile: IH x IW pixels around the pointwise tile (zero padded outside the plane)
+      float4 nosum = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int oy = y0 * s - d, ox = x0 * s - d;
+      if (GTWO) {
+        if (a.g_mode == RCV_LOAD_GRAD_ENC) wstage_tile<RCV_LOAD_GRAD_ENC, UNR, false, FOLD>(a.g, a.g_aux, a.g_c, gl, tid, NT, QG, ca0, a.CA, ng_pix, a.fdIW, a.IW, a.IW, n * a.H, oy, ox, a.H, a.W, a.SG, nosum);
+        else wstage_tile<RCV_LOAD_GRAD_DEC, UNR, false, FOLD>(a.g, a.g_aux, a.g_c, gl, tid, NT, QG, ca0, a.CA, ng_pix, a.fdIW, a.IW, a.IW, n * a.H, oy, ox, a.H, a.W, a.SG, nosum);
+      } else {
+        switch (a.g_mode) {
+          case RCV_LOAD_PLAIN: wstage_tile<RCV_LOAD_PLAIN, UNR, false, FOLD>(a.g, a.g_aux, a.g_c, gl, tid, NT, QG, ca0, a.CA, ng_pix, a.fdIW, a.IW, a.IW, n * a.H, oy, ox, a.H, a.W, a.SG, nosum); break;
+          case RCV_LOAD_AFFINE: wstage_tile<RCV_LOAD_AFFINE, UNR, false, FOLD>(a.g, a.g_aux, a.g_c, gl, tid, NT, QG, ca0, a.CA, ng_pix, a.fdIW, a.IW, a.IW, n * a.H, oy, ox, a.H, a.W, a.SG, nosum); break;
+          default: wstage_tile<RCV_LOAD_AFFINE_RELU, UNR, false, FOLD>(a.g, a.g_aux, a.g_c, gl, tid, NT, QG, ca0, a.CA, ng_pix, a.fdIW, a.IW, a.IW, n * a.H, oy, ox, a.H, a.W, a.SG, nosum); break;
         }
       }
     }
@@ -278,7 +267,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
   // while the MFMAs of k-step j run: with the reads issued right in front of their MFMAs every k-step began with an exposed LDS
   // round trip and the matrix pipe of the 16 x 16 tile was 36 % busy.  (The 36-MFMA k-steps of the wave-specialised tiles hide it
   // by themselves: measured, no difference there.)
-  constexpr bool PIPE = !SPEC;
+  constexpr bool PIPE = true;
   auto contract = [&](const float* pl, const float* gl) {
     if (PIPE) {
       // (reads are unconditional -- past the end they repeat the last k-step and are discarded: behind a branch the compiler
@@ -346,7 +335,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
       }
     }
   }
-  if (consumer && wave_k == 0) {
+  if (consumer && wave_k == 0 && !(a.dbg & (1u << 23))) {
 #pragma unroll
     for (int t = 0; t < NACC; ++t) {
       int tap, ca;
@@ -429,6 +418,11 @@ static const WTile kWT[] = {
     {1, 1, 1, 1, 4, 0, 0},  // 6: 16 x 16
     {1, 1, 1, 1, 4, 2, 0},  // 7: 16 x (9 taps x <=3 ch folded into 2 blocks)
     {1, 1, 1, 1, 4, 5, 0},  // 8: 16 x (9 taps x <=8 ch folded into 5 blocks)
+    {2, 1, 1, 1, 4, 0, 1},  // 9..13: tiles 4..8 with producer/consumer waves
+    {1, 2, 1, 1, 4, 0, 1},
+    {1, 1, 1, 1, 4, 0, 1},
+    {1, 1, 1, 1, 4, 2, 1},
+    {1, 1, 1, 1, 4, 5, 1},
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, bool SPEC>
@@ -460,6 +454,7 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   RCV_CHECK_ARG((s == 1 || s == 2) && (d == 1 || d == 2), "wgrad: stride %d dilation %d unsupported", s, d);
   RCV_CHECK_ARG(Hp == (H - 1) / s + 1 && Wp == (W - 1) / s + 1, "wgrad: pointwise plane %dx%d does not match %dx%d / %d", Hp, Wp, H, W, s);
   RCV_CHECK_ARG(CB % 4 == 0, "wgrad: pointwise channels %d must be a multiple of 4", CB);
+  RCV_CHECK_ARG((size_t)N * H * W * CA < (1ull << 31) && (size_t)N * Hp * Wp * CB < (1ull << 31), "wgrad: operand exceeds 2^31 elements (32-bit offsets)");
   const bool nchw = op->i[RCV_I_INMODE] == RCV_LOAD_NCHW;
   if (nchw) RCV_CHECK_ARG(CA <= 4, "wgrad: NCHW gathered operand supports <=4 channels");
   else RCV_CHECK_ARG(CA % 4 == 0, "wgrad: gathered channels %d must be a multiple of 4", CA);
@@ -486,6 +481,7 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
     }
   }
   RCV_CHECK_ARG(pl->tile >= 0, "wgrad: no tile for %d x %d channels", CB, CA);
+  if (pl->tile >= 4 && pl->tile <= 8 && RCV_ENV("RCV_WGRAD_SPEC")) pl->tile += 5;
   const WTile& wt = kWT[pl->tile];
   const int QG = fold ? ceil_div(CA, 4) : wt.cat() / 4;
   pl->SP = wt.cbt() % 32 == 0 ? wt.cbt() + 16 : wt.cbt();
@@ -596,7 +592,7 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   }
   if (query) {
     const WTile& wt = kWT[pl.tile];
-    snprintf(query->label, sizeof(query->label), "wgrad_mfma<%d,%d,%d,%d,%d,f%d>", wt.WM, wt.WN, wt.WAVES_M, wt.WAVES_N, wt.WAVES_K, wt.NBF);
+    snprintf(query->label, sizeof(query->label), "wgrad_mfma<%d,%d,%d,%d,%d,f%d%s>", wt.WM, wt.WN, wt.WAVES_M, wt.WAVES_N, wt.WAVES_K, wt.NBF, pl.tile >= 9 ? ",pc" : "");
     query->n_part = 0;
     query->n_split = pl.nsplit;
     query->part_bytes = (size_t)pl.nsplit * (9 * (size_t)pl.CBP * pl.CAP + pl.CBP) * sizeof(float);
@@ -635,6 +631,11 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     case 5: return wlaunch_inst<1, 2, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s, h->device);
     case 6: return wlaunch_inst<1, 1, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s, h->device);
     case 7: return wlaunch_inst<1, 1, 1, 1, 4, 2, false>(a, g_two, pl.grid, pl.lds, s, h->device);
-    default: return wlaunch_inst<1, 1, 1, 1, 4, 5, false>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 8: return wlaunch_inst<1, 1, 1, 1, 4, 5, false>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 9: return wlaunch_inst<2, 1, 1, 1, 4, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 10: return wlaunch_inst<1, 2, 1, 1, 4, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 11: return wlaunch_inst<1, 1, 1, 1, 4, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
+    case 12: return wlaunch_inst<1, 1, 1, 1, 4, 2, true>(a, g_two, pl.grid, pl.lds, s, h->device);
+    default: return wlaunch_inst<1, 1, 1, 1, 4, 5, true>(a, g_two, pl.grid, pl.lds, s, h->device);
   }
 }
