@@ -132,6 +132,7 @@ enum {
 #define RCV_F_DBG_NOSTAGE (1u << 20)
 #define RCV_F_DBG_NOSKIP  (1u << 22)
 #define RCV_F_DBG_NOMFMA  (1u << 21)
+#define RCV_F_DBG_NOEPI   (1u << 23)   /* filter gradient: skip the partial-filter stores (ablation timing only) */
 
 /* integer slots */
 enum {

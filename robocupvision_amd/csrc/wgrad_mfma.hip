@@ -335,7 +335,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
       }
     }
   }
-  if (consumer && wave_k == 0 && !(a.dbg & (1u << 23))) {
+  if (consumer && wave_k == 0 && !(a.dbg & RCV_F_DBG_NOEPI)) {
 #pragma unroll
     for (int t = 0; t < NACC; ++t) {
       int tap, ca;
@@ -418,11 +418,6 @@ static const WTile kWT[] = {
     {1, 1, 1, 1, 4, 0, 0},  // 6: 16 x 16
     {1, 1, 1, 1, 4, 2, 0},  // 7: 16 x (9 taps x <=3 ch folded into 2 blocks)
     {1, 1, 1, 1, 4, 5, 0},  // 8: 16 x (9 taps x <=8 ch folded into 5 blocks)
-    {2, 1, 1, 1, 4, 0, 1},  // 9..13: tiles 4..8 with producer/consumer waves
-    {1, 2, 1, 1, 4, 0, 1},
-    {1, 1, 1, 1, 4, 0, 1},
-    {1, 1, 1, 1, 4, 2, 1},
-    {1, 1, 1, 1, 4, 5, 1},
 };
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, bool SPEC>
@@ -481,7 +476,6 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
     }
   }
   RCV_CHECK_ARG(pl->tile >= 0, "wgrad: no tile for %d x %d channels", CB, CA);
-  if (pl->tile >= 4 && pl->tile <= 8 && RCV_ENV("RCV_WGRAD_SPEC")) pl->tile += 5;
   const WTile& wt = kWT[pl->tile];
   const int QG = fold ? ceil_div(CA, 4) : wt.cat() / 4;
   pl->SP = wt.cbt() % 32 == 0 ? wt.cbt() + 16 : wt.cbt();
@@ -491,9 +485,16 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   int per_cu = wt.SPEC ? 1 : 2;                     // SPEC: 512 threads, two LDS buffers => one workgroup per CU
   if (const char* ev = RCV_ENV("RCV_WGRAD_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4 && !wt.SPEC) per_cu = o; }
   const size_t budget = (wt.SPEC ? 78 : 160 / per_cu) * 1024 / sizeof(float);   // SPEC: per buffer
-  // Pixel tile: among the (row segment, rows) shapes that fit the LDS budget, the one that stages the fewest global bytes per
-  // pointwise pixel (the gathered tile carries a halo of 2*dil rows and columns: a 1 x 80 tile of a stride-1 layer reads its gathered
-  // operand 3.1 times, a 4 x 40 tile 1.6 times); ties go to the larger tile.  RCV_WGRAD_WIDE=1 restores "widest row segment first".
+  // Pixel tile: among the (row segment, rows) shapes that fit the LDS budget, the one with the lowest estimated time
+  //     t ~ (1 + 3 / k-steps per wave and tile) / fill  +  w * halo,
+  //   fill = real pointwise pixels / MFMA pixel slots of the launch (row segments padded to 4 columns, ragged last tiles, workgroups
+  //          that get one tile fewer than the others or none at all: 480 tiles on 64 workgroups run 8 rounds with 94 % of the slots used),
+  //   halo = staged global bytes per pointwise pixel relative to reading every operand element once (the gathered tile carries a
+  //          halo of 2*dil rows and columns: a 1 x 80 tile of a stride-1 layer reads its gathered operand 3.1 times, a 4 x 40 tile 1.6 times);
+  //   w: the producer/consumer tiles hide their staging behind the MFMAs (small w), the shared-role tiles add it to them.
+  // RCV_WGRAD_WIDE=1 (experiments) restores "widest row segment first".
+  const int ctiles_plan = ceil_div(pl->CBP, wt.cbt()) * (fold ? 1 : ceil_div(pl->CAP, wt.cat()));
+  const int wg_max = (per_cu * h->num_cus) / ctiles_plan > 0 ? (per_cu * h->num_cus) / ctiles_plan : 1;
   int bestR = 0, bestWt = 0;
   {
     const int m1 = op->i[RCV_I_INMODE], m2 = op->i[RCV_I_INMODE2];
@@ -501,6 +502,7 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
     const double cP = (double)CB * ((m2 == RCV_LOAD_GRAD_ENC || m2 == RCV_LOAD_GRAD_DEC) ? 2 : 1);
     const bool wide_first = RCV_ENV("RCV_WGRAD_WIDE") != nullptr;
     const int max_px = wt.SPEC ? 1024 : 640;
+    const double w_halo = wt.SPEC ? 0.15 : 1.0;
     double best_cost = 1e30;
     int prevWt = 0;
     for (int nx = 1; nx <= Wp; ++nx) {                 // every distinct segment width (~2 sqrt(Wp) of them)
@@ -514,19 +516,29 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
       if ((long)budget - fixed < per_row) continue;
       if (((long)budget - fixed) / per_row < rmax) rmax = ((long)budget - fixed) / per_row;
       if (rmax > Hp) rmax = Hp;
+      int prevRe = 0;
       for (int R = (int)rmax; R >= 1; --R) {
         const int IH = (R - 1) * s + 2 * d + 1;
         if (R * Wt4 > max_px || IH * IW >= 65536) continue;
         if ((size_t)R * Wt4 * pl->SP + (size_t)IH * IW * pl->SG > budget) continue;
         const int Re = ceil_div(Hp, ceil_div(Hp, R));            // rows actually used (equal row groups)
-        const int IHe = (Re - 1) * s + 2 * d + 1;
-        const double ntile = (double)ceil_div(Wp, Wt) * ceil_div(Hp, Re);   // ragged last tiles cost as much as full ones
-        const double cost = ntile * ((double)Re * Wt4 * cP + (double)IHe * IW * cG) / ((double)Hp * Wp);
+        if (Re == prevRe) continue;
+        prevRe = Re;
         if (wide_first) { if (bestR == 0) { bestR = R; bestWt = Wt; } break; }
-        if (cost < best_cost * 0.995 || (cost < best_cost * 1.005 && R * Wt > bestR * bestWt)) {
-          best_cost = cost < best_cost ? cost : best_cost; bestR = R; bestWt = Wt;
+        const int IHe = (Re - 1) * s + 2 * d + 1;
+        const long ntile = (long)N * ceil_div(Wp, Wt) * ceil_div(Hp, Re);   // ragged last tiles cost as much as full ones
+        const long wgs = ntile < wg_max ? ntile : wg_max;
+        const long rounds = ceil_div(ntile, wgs);
+        // (a launch that cannot give every CU a workgroup is charged for the idle ones as well)
+        const double fill = (double)N * Hp * Wp / ((double)rounds * wg_max * Re * Wt4);
+        const double halo = ((double)Re * Wt4 * cP + (double)IHe * IW * cG) / ((double)Re * Wt * (cP + (double)s * s * cG));
+        // (every tile also costs a barrier and a cold start of the operand pipeline: about three k-steps of a wave's matrix time)
+        const double per_tile = 1.0 + 3.0 * wt.WAVES_K / (Re * Wt4 / 4);
+        const double cost = per_tile / fill + w_halo * halo;
+        if (cost < best_cost * 0.995 || (cost < best_cost * 1.005 && Re * Wt > bestR * bestWt)) {
+          best_cost = cost < best_cost ? cost : best_cost; bestR = Re; bestWt = Wt;
         }
-        break;                                                   // fewer rows of the same segment only add halo
+        if (Re * 3 < (int)rmax) break;                           // much smaller tiles only add halo and barriers
       }
       if (wide_first && bestR) break;
     }
@@ -592,7 +604,7 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   }
   if (query) {
     const WTile& wt = kWT[pl.tile];
-    snprintf(query->label, sizeof(query->label), "wgrad_mfma<%d,%d,%d,%d,%d,f%d%s>", wt.WM, wt.WN, wt.WAVES_M, wt.WAVES_N, wt.WAVES_K, wt.NBF, pl.tile >= 9 ? ",pc" : "");
+    snprintf(query->label, sizeof(query->label), "wgrad_mfma<%d,%d,%d,%d,%d,f%d>", wt.WM, wt.WN, wt.WAVES_M, wt.WAVES_N, wt.WAVES_K, wt.NBF);
     query->n_part = 0;
     query->n_split = pl.nsplit;
     query->part_bytes = (size_t)pl.nsplit * (9 * (size_t)pl.CBP * pl.CAP + pl.CBP) * sizeof(float);
@@ -631,11 +643,6 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     case 5: return wlaunch_inst<1, 2, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s, h->device);
     case 6: return wlaunch_inst<1, 1, 1, 1, 4, 0, false>(a, g_two, pl.grid, pl.lds, s, h->device);
     case 7: return wlaunch_inst<1, 1, 1, 1, 4, 2, false>(a, g_two, pl.grid, pl.lds, s, h->device);
-    case 8: return wlaunch_inst<1, 1, 1, 1, 4, 5, false>(a, g_two, pl.grid, pl.lds, s, h->device);
-    case 9: return wlaunch_inst<2, 1, 1, 1, 4, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
-    case 10: return wlaunch_inst<1, 2, 1, 1, 4, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
-    case 11: return wlaunch_inst<1, 1, 1, 1, 4, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
-    case 12: return wlaunch_inst<1, 1, 1, 1, 4, 2, true>(a, g_two, pl.grid, pl.lds, s, h->device);
-    default: return wlaunch_inst<1, 1, 1, 1, 4, 5, true>(a, g_two, pl.grid, pl.lds, s, h->device);
+    default: return wlaunch_inst<1, 1, 1, 1, 4, 5, false>(a, g_two, pl.grid, pl.lds, s, h->device);
   }
 }

@@ -5,7 +5,7 @@ O=gpurun_out/abwg.log
 : > $O
 timeout -k 10 400 python -m pytest tests/test_gpu_blocks.py tests/test_gpu_net.py -m gpu -x -q -p no:cacheprovider > gpurun_out/abwg_tests.log 2>&1
 echo "tests exit=$?" >> $O; tail -1 gpurun_out/abwg_tests.log >> $O
-A=robocupvision_amd/librcv_A.so; B=robocupvision_amd/librcv.so
+A=robocupvision_amd/${ALIB:-librcv_A.so}; B=robocupvision_amd/librcv.so
 R=${1:-2}
 bash scripts/ab.sh $A $B $R -- wgrad 32 30 40 128 128 --mode affine --mode2 grad_enc >> $O
 bash scripts/ab.sh $A $B $R -- wgrad 32 60 80 64 64 --mode affine --mode2 grad_enc >> $O
@@ -24,6 +24,6 @@ for line in open(sys.argv[1]):
     if m: d[(m.group(3), m.group(1))].append(float(m.group(4)))
     elif "tests" in line or "passed" in line or "failed" in line: print(line.strip())
 for k in sorted(set(k[0] for k in d)):
-    a, b = d.get((k, "librcv_A.so"), []), d.get((k, "librcv.so"), [])
+    a, b = [v for (kk, l), vv in d.items() if kk == k and l != "librcv.so" for v in vv], d.get((k, "librcv.so"), [])
     if a and b: print("%-84s A %.4f  B %.4f  B/A %.3f" % (k[:84], sum(a)/len(a), sum(b)/len(b), (sum(b)/len(b))/(sum(a)/len(a))))
 PY
