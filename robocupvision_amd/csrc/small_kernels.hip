@@ -784,7 +784,7 @@ template <bool MET>
 __global__ void adam_l1_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                const float* __restrict__ lr_elem, size_t n, float lr, float b1, float b2, float eps, float decay,
                                float grad_scale, int step_host, const int* __restrict__ step_dev, double* part,
-                               const float* __restrict__ loss_stats, double* metrics, const uint8_t* __restrict__ prune) {
+                               const float* __restrict__ loss_stats, double* metrics, const uint8_t* __restrict__ prune, int vec) {
   // bias corrections of step t (1-based): t comes from the record, or -- when the whole training step is replayed as a captured
   // graph and the host cannot change launch arguments -- from a device counter the caller advances ahead of this launch
   __shared__ float s_bc[2];
@@ -796,20 +796,39 @@ __global__ void adam_l1_kernel(float* __restrict__ p, const float* __restrict__ 
   __syncthreads();
   const float bc1 = s_bc[0], bc2_sqrt = s_bc[1];
   float asum = 0.f;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
-    const float pv = p[e];
+  auto update = [&](float pv, float gv, float& mv, float& vv, float lre, bool pruned) -> float {
     if (MET) asum += fabsf(pv);                       // l1reg(model) runs over every parameter, stepped or not
-    const float lre = lr_elem ? lr_elem[e] : lr;
-    if (lre == 0.f) continue;                         // parameter without a gradient (outside the graph / the groups): untouched, as under torch.optim.Adam
+    if (lre == 0.f) return pv;                        // parameter without a gradient (outside the graph / the groups): untouched, as under torch.optim.Adam
     const float sg = pv > 0.f ? 1.f : (pv < 0.f ? -1.f : 0.f);
-    float gr = fmaf(decay, sg, g[e] * grad_scale);
-    if (prune && prune[e]) gr = 0.f;                  // train.py:59-65: param.grad[indices] = 0 after backward (the L1 part included)
-    const float mm = b1 * m[e] + (1.f - b1) * gr;
-    const float vv = b2 * v[e] + (1.f - b2) * gr * gr;
-    m[e] = mm; v[e] = vv;
+    float gr = fmaf(decay, sg, gv * grad_scale);
+    if (pruned) gr = 0.f;                             // train.py:59-65: param.grad[indices] = 0 after backward (the L1 part included)
+    mv = b1 * mv + (1.f - b1) * gr;
+    vv = b2 * vv + (1.f - b2) * gr * gr;
     const float denom = sqrtf(vv) / bc2_sqrt + eps;
     const float step = lre / bc1;
-    p[e] = pv - step * (mm / denom);
+    return pv - step * (mv / denom);
+  };
+  // four elements per thread and iteration (the flat buffers come from one allocation each: 16-byte aligned), scalar tail
+  const size_t n4 = vec ? n / 4 : 0;
+  const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsize = (size_t)gridDim.x * blockDim.x;
+  for (size_t e = gtid; e < n4; e += gsize) {
+    float4 pv = reinterpret_cast<const float4*>(p)[e];
+    const float4 gv = reinterpret_cast<const float4*>(g)[e];
+    float4 mv = reinterpret_cast<const float4*>(m)[e], vv = reinterpret_cast<const float4*>(v)[e];
+    const float4 le = lr_elem ? reinterpret_cast<const float4*>(lr_elem)[e] : make_float4(lr, lr, lr, lr);
+    const uchar4 pr = prune ? reinterpret_cast<const uchar4*>(prune)[e] : make_uchar4(0, 0, 0, 0);
+    pv.x = update(pv.x, gv.x, mv.x, vv.x, le.x, pr.x != 0);
+    pv.y = update(pv.y, gv.y, mv.y, vv.y, le.y, pr.y != 0);
+    pv.z = update(pv.z, gv.z, mv.z, vv.z, le.z, pr.z != 0);
+    pv.w = update(pv.w, gv.w, mv.w, vv.w, le.w, pr.w != 0);
+    reinterpret_cast<float4*>(p)[e] = pv;
+    reinterpret_cast<float4*>(m)[e] = mv;
+    reinterpret_cast<float4*>(v)[e] = vv;
+  }
+  for (size_t e = 4 * n4 + gtid; e < n; e += gsize) {
+    float mv = m[e], vv = v[e];
+    p[e] = update(p[e], g[e], mv, vv, lr_elem ? lr_elem[e] : lr, prune && prune[e]);
+    m[e] = mv; v[e] = vv;
   }
   if (MET) {
     __shared__ int is_last;
@@ -957,6 +976,16 @@ __global__ void bwd_stats_kernel(const float* __restrict__ g, const float* __res
 static inline int stream_grid(const rcv_handle* h, size_t work_items, int block) {
   size_t g = (work_items + block - 1) / block;
   const size_t cap = (size_t)h->num_cus * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// optimizer kernels: four elements per thread and iteration, at most two workgroups per CU (the metrics variant ends with one
+// device-scope ticket per workgroup: 2048 of them on one address cost more than the update itself)
+static inline int adam_grid(const rcv_handle* h, size_t n) {
+  size_t g = (n / 4 + 255) / 256;
+  const size_t cap = (size_t)h->num_cus * 2;
   if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
@@ -1178,7 +1207,7 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     case RCV_OP_ADAM_L1: {
       const size_t n = (size_t)(uint32_t)op->i[RCV_I_COUNT];
       if (query) {                                       // workspace of the metrics variant: one double per workgroup + the ticket
-        query->n_part = stream_grid(h, n, 256);
+        query->n_part = adam_grid(h, n);
         query->part_bytes = ((size_t)query->n_part + 1) * sizeof(double);
         return RCV_OK;
       }
@@ -1186,19 +1215,22 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       const int* step_dev = (const int*)op->p[RCV_P_IN_AUX];
       RCV_CHECK_ARG(n > 0 && (step >= 1 || step_dev) && op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_X0] && op->p[RCV_P_X1], "adam: bad operand");
       const float b1 = op->f[1], b2 = op->f[2];
-      const int g = stream_grid(h, n, 256);
+      // 16-byte vector path when every buffer is aligned for it (flat buffers of whole allocations are); otherwise element by element
+      const int vec = ((((uintptr_t)op->p[RCV_P_IN] | (uintptr_t)op->p[RCV_P_IN2] | (uintptr_t)op->p[RCV_P_X0] | (uintptr_t)op->p[RCV_P_X1] |
+                         (uintptr_t)op->p[RCV_P_X2]) & 15) == 0 && ((uintptr_t)op->p[RCV_P_X5] & 3) == 0) ? 1 : 0;
+      const int g = adam_grid(h, n);
       double* part = (double*)op->p[RCV_P_PART];
       if (op->p[RCV_P_X3]) {
         RCV_CHECK_ARG(part && op->p[RCV_P_X4] && op->i[RCV_I_NPART] == g, "adam + metrics: needs loss stats and a %d-row workspace (rcv_op_workspace)", g);
         hipLaunchKernelGGL(adam_l1_kernel<true>, dim3(g), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
                            (float*)op->p[RCV_P_X0], (float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], n, op->f[0], b1, b2, op->f[3],
                            op->f[4], op->f[5], step, step_dev, part, (const float*)op->p[RCV_P_X4], (double*)op->p[RCV_P_X3],
-                           (const uint8_t*)op->p[RCV_P_X5]);
+                           (const uint8_t*)op->p[RCV_P_X5], vec);
       } else {
         hipLaunchKernelGGL(adam_l1_kernel<false>, dim3(g), dim3(256), 0, s, (float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
                            (float*)op->p[RCV_P_X0], (float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], n, op->f[0], b1, b2, op->f[3],
                            op->f[4], op->f[5], step, step_dev, (double*)nullptr, (const float*)nullptr, (double*)nullptr,
-                           (const uint8_t*)op->p[RCV_P_X5]);
+                           (const uint8_t*)op->p[RCV_P_X5], vec);
       }
       break;
     }
