@@ -223,17 +223,30 @@ __global__ void concat_kernel(const float* __restrict__ t, const float* __restri
 #define CE_MAX_C 8
 // FUSED: the classifier input up = relu(t*c0+c1) + f(r) (decoder block output + skip, model.py:509) is formed here from the
 // block's raw tensors instead of being materialised by RCV_OP_COMBINE (saves one tensor write and one read at full resolution).
+// (raw loads and the arithmetic are separate so that the streaming loops can request pixel i+1 before they work on pixel i)
 template <int CIN, bool FUSED>
-__device__ __forceinline__ void cls_load_up(float (&v)[CIN], const float* __restrict__ x, const float* __restrict__ tc,
-                                            const float* __restrict__ r, const float* __restrict__ rc, int mode2, size_t p) {
+struct ClsRaw { float4 a[CIN / 4]; float4 b[FUSED ? CIN / 4 : 1]; };
+
+template <int CIN, bool FUSED>
+__device__ __forceinline__ void cls_load_raw(ClsRaw<CIN, FUSED>& o, const float* __restrict__ x, const float* __restrict__ r, size_t p) {
 #pragma unroll
   for (int q = 0; q < CIN / 4; ++q) {
-    float4 a = sld4(x + p * CIN + 4 * q);
+    o.a[q] = sld4(x + p * CIN + 4 * q);
+    if (FUSED) o.b[FUSED ? q : 0] = sld4(r + p * CIN + 4 * q);
+  }
+}
+
+template <int CIN, bool FUSED>
+__device__ __forceinline__ void cls_form_up(float (&v)[CIN], const ClsRaw<CIN, FUSED>& raw, const float* __restrict__ tc,
+                                            const float* __restrict__ rc, int mode2) {
+#pragma unroll
+  for (int q = 0; q < CIN / 4; ++q) {
+    float4 a = raw.a[q];
     if (FUSED) {
       const float4 s = sld4(tc + 4 * q), h = sld4(tc + CIN + 4 * q);
       a.x = fmaxf(fmaf(a.x, s.x, h.x), 0.f); a.y = fmaxf(fmaf(a.y, s.y, h.y), 0.f);
       a.z = fmaxf(fmaf(a.z, s.z, h.z), 0.f); a.w = fmaxf(fmaf(a.w, s.w, h.w), 0.f);
-      float4 b = sld4(r + p * CIN + 4 * q);
+      float4 b = raw.b[FUSED ? q : 0];
       if (mode2 != RCV_LOAD_PLAIN) {
         const float4 s2 = sld4(rc + 4 * q), h2 = sld4(rc + CIN + 4 * q);
         b.x = fmaf(b.x, s2.x, h2.x); b.y = fmaf(b.y, s2.y, h2.y); b.z = fmaf(b.z, s2.z, h2.z); b.w = fmaf(b.w, s2.w, h2.w);
@@ -243,6 +256,14 @@ __device__ __forceinline__ void cls_load_up(float (&v)[CIN], const float* __rest
     }
     v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
   }
+}
+
+template <int CIN, bool FUSED>
+__device__ __forceinline__ void cls_load_up(float (&v)[CIN], const float* __restrict__ x, const float* __restrict__ tc,
+                                            const float* __restrict__ r, const float* __restrict__ rc, int mode2, size_t p) {
+  ClsRaw<CIN, FUSED> raw;
+  cls_load_raw<CIN, FUSED>(raw, x, r, p);
+  cls_form_up<CIN, FUSED>(v, raw, tc, rc, mode2);
 }
 
 // CE: the weighted cross-entropy partial sums, the arg-max mask and the pixel-accuracy count of RCV_OP_CE_FWD are taken from the
@@ -260,6 +281,7 @@ __global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restr
   __syncthreads();
   double a_nll = 0.0, a_w = 0.0, a_ok = 0.0;
   const size_t total = (size_t)N * HW;
+  // (no software prefetch here: measured 0.205 vs 0.194 ms -- this kernel already streams at 4.7 TB/s; the backward one gained 30 %)
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
     float v[CIN];
     cls_load_up<CIN, FUSED>(v, x, tc, r, rc, mode2, p);
@@ -331,10 +353,21 @@ __global__ __launch_bounds__(256, 2) void cls_bwd_kernel(const float* __restrict
 #pragma unroll
   for (int k = 0; k < CIN; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
   const size_t total = (size_t)N * HW;
-  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+  // pixel i+1 (and its label) is requested before pixel i is worked on: unconditionally, the last iteration re-requests its own pixel
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  ClsRaw<CIN, FUSED> cur;
+  int64_t tcur = 0;
+  if (p < total) { cls_load_raw<CIN, FUSED>(cur, FUSED ? t : up, r, p); if (CE) tcur = target[p]; }
+  for (; p < total; p += stride) {
+    const size_t pn = p + stride < total ? p + stride : p;
+    ClsRaw<CIN, FUSED> nxt;
+    cls_load_raw<CIN, FUSED>(nxt, FUSED ? t : up, r, pn);
+    int64_t tnxt = 0;
+    if (CE) tnxt = target[pn];
     const size_t n = p / HW, hw = p % HW;
     float g[COUT], u[CIN], d[CIN];
-    cls_load_up<CIN, FUSED>(u, FUSED ? t : up, tc, r, rc, mode2, p);      // FUSED: up is re-formed from t and the skip tensor
+    cls_form_up<CIN, FUSED>(u, cur, tc, rc, mode2);                       // FUSED: up is re-formed from t and the skip tensor
     if (CE) {
       float mx = -INFINITY;
 #pragma unroll
@@ -348,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void cls_bwd_kernel(const float* __restrict
       float se = 0.f;
 #pragma unroll
       for (int c = 0; c < COUT; ++c) { g[c] = expf(g[c] - mx); se += g[c]; }
-      const int tg = (int)target[p];
+      const int tg = (int)tcur;
       const float kf = (grad_out[0] / loss_out[1]) * ((unsigned)tg < (unsigned)COUT ? (cw ? cw[tg] : 1.f) : 0.f);
       const float inv = 1.f / se;
 #pragma unroll
@@ -390,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void cls_bwd_kernel(const float* __restrict
     if (stats == RCV_STATS_BWD_DEC) {
 #pragma unroll
       for (int q = 0; q < CIN / 4; ++q) {
-        const float4 a = sld4(t + p * CIN + 4 * q);
+        const float4 a = FUSED ? cur.a[q] : sld4(t + p * CIN + 4 * q);      // FUSED: the raw decoder output is already in registers
         const float tv[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -401,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void cls_bwd_kernel(const float* __restrict
         }
       }
     }
+    cur = nxt; tcur = tnxt;
   }
   // block reduction: wave shuffles, then the 4 waves through LDS in fixed order
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
