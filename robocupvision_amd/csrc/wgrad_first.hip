@@ -157,7 +157,7 @@ bool wgrad_first_supported(const rcv_op* op) {
          (d == 1 || d == 2) && op->i[RCV_I_INMODE2] != RCV_LOAD_NCHW;
 }
 
-static inline int wf_occ() { return 2; }   // two workgroups of six waves per CU (106 registers; a third one needs <= 96 and spilled: slower)
+static inline int wf_occ() { if (const char* e = RCV_ENV("RCV_WF_OCC")) { const int o = atoi(e); if (o >= 1 && o <= 6) return o; } return 2; }   // two workgroups of six waves per CU (106 registers; a third one needs <= 96 and spilled: slower)
 
 static inline int wf_tiles(const rcv_op* op, int* tx, int* ty) {
   *tx = ceil_div(op->i[RCV_I_WO], 64); *ty = ceil_div(op->i[RCV_I_HO], 8);

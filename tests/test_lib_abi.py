@@ -75,3 +75,39 @@ def test_shipped_library_does_not_read_the_environment():
     if out.returncode != 0:
         pytest.skip("nm not available")
     assert not any(tok.split("@")[0] == "getenv" for tok in out.stdout.split()), "librcv.so imports getenv: an experiment build was left in the tree"
+
+
+def test_planner_accepts_every_layer_shape_of_the_networks():
+    """Planner sweep (no GPU): every conv / transposed-conv / filter-gradient record the ROBO-UNet, U-Net and PB_FCN graphs produce at the
+    BASELINE sizes and at ragged / tiny planes gets a plan (tile within the LDS limit, workspace size, label), for 256 CUs and for a small
+    part (64 CUs).  A shape for which tile selection finds nothing would otherwise only show up as a failed launch on the GPU."""
+    planes = [(32, 480, 640), (64, 120, 160), (32, 240, 320), (2, 48, 64), (1, 32, 48), (3, 37, 53), (1, 9, 11), (5, 130, 70)]
+    chans = [(3, 8), (8, 8), (8, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128), (128, 64), (24, 40), (4, 12)]
+    labels = set()
+    for cus in (256, 64):
+        h = L.planner_handle(cus)
+        for (n, H, W) in planes:
+            for (ci, co) in chans:
+                for s in (1, 2):
+                    for d in ((1, 2) if s == 1 else (1,)):
+                        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+                        if ci >= 4:
+                            for mode in (L.LOAD_AFFINE, L.LOAD_GRAD_ENC):
+                                op = L.make_op(L.OP_CONV, L.F_BIAS, n=n, h=H, w=W, cin=ci, cout=co, ho=Ho, wo=Wo, stride=s, dil=d,
+                                               inmode=mode, stats=L.STATS_FWD)
+                                assert L.op_workspace(h, op) >= 0
+                                labels.add(L.OpList([op]).labels(h)[0].split("<")[0])
+                            op = L.make_op(L.OP_WGRAD, L.F_BIAS, n=n, h=H, w=W, cin=ci, ho=Ho, wo=Wo, cout=co, stride=s, dil=d,
+                                           inmode=L.LOAD_AFFINE, inmode2=L.LOAD_GRAD_ENC)
+                            assert L.op_workspace(h, op) > 0 and op.i[L.RCV_I_NSPLIT] >= 1
+                            labels.add(L.OpList([op]).labels(h)[0].split("<")[0])
+                        elif d == 1 or s == 1:
+                            op = L.make_op(L.OP_WGRAD, L.F_BIAS, n=n, h=H, w=W, cin=ci, ho=Ho, wo=Wo, cout=co, stride=s, dil=d,
+                                           inmode=L.LOAD_NCHW, inmode2=L.LOAD_GRAD_ENC)
+                            assert L.op_workspace(h, op) > 0
+                            labels.add(L.OpList([op]).labels(h)[0].split("<")[0])
+                if ci >= 4 and co % 4 == 0:
+                    op = L.make_op(L.OP_TCONV, L.F_BIAS, n=n, h=H, w=W, cin=ci, cout=co, ho=2 * H, wo=2 * W, stride=2, dil=1,
+                                   inmode=L.LOAD_AFFINE, stats=L.STATS_FWD)
+                    assert L.op_workspace(h, op) >= 0
+    assert {"wgrad_mfma", "wgrad_first", "conv_dma", "convs_mfma"} <= labels, labels
