@@ -306,6 +306,23 @@ def test_adam_l1_named_entry_points_vs_torch():
     got = metrics.cpu().tolist()
     for a, b in zip(got, exp):
         assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), (got, exp)
+    # buffers that are not 16-byte aligned (views one float into an allocation) take the element-by-element path: same bits
+    step_fn = lib.rcv_adam_l1_step
+    step_fn.restype = C.c_int
+    step_fn.argtypes = [C.c_void_p] * 6 + [C.c_int64] + [C.c_float] * 5 + [C.c_int, C.c_float, C.c_void_p]
+    grad = torch.randn(n, generator=g).to(dev)
+    outs = []
+    for shift in (0, 1):
+        bufs = [torch.zeros(n + 4, device=dev) for _ in range(4)]
+        pp, gg, mm, vv = (b[shift:shift + n] for b in bufs)
+        pp.copy_(p); gg.copy_(grad); mm.copy_(m); vv.copy_(v)
+        assert (pp.data_ptr() % 16 == 0) == (shift == 0)
+        rc = step_fn(h, pp.data_ptr(), gg.data_ptr(), mm.data_ptr(), vv.data_ptr(), None, n, lr, 0.9, 0.999, 1e-8, decay, 4, 1.0, st)
+        assert rc == 0, lib.rcv_last_error()
+        torch.cuda.synchronize()
+        outs.append((pp.clone(), mm.clone(), vv.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def _abi_conv(x_nhwc, w, mode_wino, relu_bias=None):
