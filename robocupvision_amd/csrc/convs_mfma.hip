@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
         const bool inside = pix < npix && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
         const int gyc = gy < 0 ? 0 : (gy < a.H ? gy : a.H - 1), gxc = gx < 0 ? 0 : (gx < a.W ? gx : a.W - 1);
         okmask |= (inside ? 1u : 0u) << u;
-        const size_t off = ((size_t)(ti.n * a.H + gyc) * a.W + gxc) * a.Cin + 4 * q;
+        const int off = ((ti.n * a.H + gyc) * a.W + gxc) * a.Cin + 4 * q;      // 32-bit: the host checks that the tensors stay below 2^31 elements
         px[u] = ld4(a.in + off);
         if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
       }
@@ -213,14 +213,21 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
         if (a.stats == RCV_STATS_BWD_DEC) { e0 = ld4(a.epi_c + co); e1 = ld4(a.epi_c + a.Cout + co); }
         if (a.stats == RCV_STATS_BWD_DEC || a.stats == RCV_STATS_BWD_ENC) mu = ld4(a.epi_c + 2 * a.Cout + co);
       }
-      // first every load of the skip gradient / statistics operand of this co-block (independent, in flight together),
-      // then the arithmetic and the stores
-      size_t offs[WN];
-      bool oks[WN];
-      float4 rr[WN], ee[WN];
+      // first the loads of the skip gradient / statistics operand of (a group of) the pixel blocks of this co-block (independent, in
+      // flight together), then the arithmetic and the stores.  Groups of at most BG blocks: with all five of the widest two-tensor tiles
+      // in one batch the kernel needed > 256 registers and the compiler parked part of the PREFETCHED input tile in scratch, i.e.
+      // waited for those loads right after issuing them
+      constexpr int BG = !TWO ? WN : (WN > 3 ? 3 : (WM >= 4 ? 2 : WN));
       const bool need_e = a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC;
 #pragma unroll
-      for (int b = 0; b < WN; ++b) {
+      for (int b0 = 0; b0 < WN; b0 += BG) {
+      int offs[BG];
+      bool oks[BG];
+      float4 rr[BG], ee[BG];
+#pragma unroll
+      for (int bb = 0; bb < BG; ++bb) {
+        const int b = b0 + bb;
+        if (b >= WN) { oks[bb] = false; offs[bb] = 0; rr[bb] = make_float4(0.f, 0.f, 0.f, 0.f); ee[bb] = rr[bb]; continue; }
         const int p = (wave * WN + b) * 16 + l15;
         const int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
         int oy = ti.y0 + ty, ox = ti.x0 + tx;
@@ -231,23 +238,24 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
         } else {
           ok = ok && oy < a.Ho && ox < a.Wo;
         }
-        oks[b] = ok;
-        offs[b] = ((size_t)(ti.n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
-        rr[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ee[b] = rr[b];
+        oks[bb] = ok;
+        offs[bb] = ((ti.n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
+        rr[bb] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ee[bb] = rr[bb];
         if (ok) {
-          if (a.flags & RCV_F_RESID) rr[b] = ld4(a.resid + offs[b]);
-          if (need_e) ee[b] = ld4(a.epi_aux + offs[b]);
+          if (a.flags & RCV_F_RESID) rr[bb] = ld4(a.resid + offs[bb]);
+          if (need_e) ee[bb] = ld4(a.epi_aux + offs[bb]);
         }
       }
 #pragma unroll
-      for (int b = 0; b < WN; ++b) {
-        if (!oks[b]) continue;
+      for (int bb = 0; bb < BG; ++bb) {
+        const int b = b0 + bb;
+        if (b >= WN || !oks[bb]) continue;
         float4 v = make_float4(acc[m][b][0] + bias.x, acc[m][b][1] + bias.y, acc[m][b][2] + bias.z, acc[m][b][3] + bias.w);
         if (a.flags & RCV_F_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        v.x += rr[b].x; v.y += rr[b].y; v.z += rr[b].z; v.w += rr[b].w;
-        *reinterpret_cast<float4*>(a.out + offs[b]) = v;
-        const float4 e = ee[b];
+        v.x += rr[bb].x; v.y += rr[bb].y; v.z += rr[bb].z; v.w += rr[bb].w;
+        *reinterpret_cast<float4*>(a.out + offs[bb]) = v;
+        const float4 e = ee[bb];
         if (a.stats == RCV_STATS_FWD) {
           s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
           s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
@@ -265,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
           s2[m][0] = fmaf(gx, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(gy, e.y - mu.y, s2[m][1]);
           s2[m][2] = fmaf(gz, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(gw, e.w - mu.w, s2[m][3]);
         }
+      }
       }
     }
     tile = ntile;
