@@ -349,9 +349,9 @@ def main():
     eng = model._get_engine()
     plans = [pl for (shape, training), pl in eng.plans.items() if training and pl.side_decided]
     if plans:      # schedule of the backward list the engine measured and kept on its first pass (engine.SIDE_STREAM_MODE)
-        out["config"]["filter_gradients_on_second_stream"] = bool(plans[0].side_on)
+        out["config"]["second_stream"] = plans[0].side_mode      # "all": filter gradients + their reductions, "reduce": reductions only, "off"
         if plans[0].side_ms:
-            out["config"]["backward_ms_two_streams_vs_one"] = [round(v, 3) for v in plans[0].side_ms]
+            out["config"]["backward_ms_all_reduce_off"] = [round(v, 3) for v in plans[0].side_ms]
     if rank == 0 and not args.no_roofline:
         rows = eng.profile_last(reps=3)
         # the optimizer launch belongs to the step as well (one RCV_OP_ADAM_L1 over the flat buffers: 28 B per parameter)

@@ -29,9 +29,9 @@ from . import _lib as L
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 SIDE_STREAM_WGRAD = not os.environ.get("RCV_NO_SIDE_STREAM")
-# "auto" (default): the first backward pass of a plan times itself with the filter gradients on the second stream and on the
-# caller's stream (3 runs each) and keeps the faster schedule -- the overlap gains 4 % on ROBO-UNet 640x480 and loses 1 % on
-# the U-Net configuration (the co-resident kernels compete for LDS); "1": always overlapped, no measurement.
+# "auto" (default): the first backward pass of a plan times itself under three schedules (3 runs each) -- filter gradients, their
+# reductions and the bias memsets on the library's second stream ("all"), only the reductions and memsets there ("reduce"), everything on
+# the caller's stream ("off") -- and keeps the fastest; "1" / "all" / "reduce" / "off": that schedule, no measurement.
 SIDE_STREAM_MODE = os.environ.get("RCV_SIDE_STREAM", "auto")
 FUSE_UP_INTO_CLS = not os.environ.get("RCV_NO_FUSED_UP")
 CLS3_PAD = 8                    # class channels of the 3x3 classifier (v2) are padded to this many NHWC channels
@@ -178,7 +178,8 @@ class Plan:
         self.ce = None                       # lazily built op lists with the cross entropy fused into the classifier ops
         self.side_decided = False            # filter gradients on the second stream: measured on the first backward pass
         self.side_on = True
-        self.side_ms = None                  # (ms with the second stream, ms without) of that measurement
+        self.side_mode = "all"              # one of Engine.SIDE_MODES
+        self.side_ms = None                  # backward ms under each of Engine.SIDE_MODES, from that measurement
         self.bytes = 0
 
 
@@ -901,24 +902,33 @@ class Engine:
         self._run_backward(plan, plan.bwd)
         return plan
 
+    SIDE_MODES = ("all", "reduce", "off")      # which backward ops run on the library's second stream
+
     @staticmethod
-    def _set_side(ops: L.OpList, on: bool):
+    def _set_side(ops: L.OpList, mode):
+        """mode: "all" (True) = filter gradients, their reductions and the bias memsets; "reduce" = only the reductions and memsets (small
+        bandwidth-bound launches that fit beside the next data-gradient kernel, while the filter-gradient kernels themselves keep
+        the whole chip); "off" (False) = everything on the caller's stream."""
+        mode = {True: "all", False: "off"}.get(mode, mode)
         for k in range(ops.n):
             op = ops.arr[k]
             if op.kind in (L.OP_WGRAD, L.OP_WGRAD_REDUCE, L.OP_MEMSET):
+                on = mode == "all" or (mode == "reduce" and op.kind != L.OP_WGRAD)
                 op.flags = (op.flags | L.F_SIDE_STREAM) if on else (op.flags & ~L.F_SIDE_STREAM)
 
     def _decide_side_stream(self, plan: Plan, ops: L.OpList):
-        """Times the backward list both ways (it only overwrites engine buffers: re-running it is harmless) and keeps the faster."""
+        """Times the backward list under each schedule (it only overwrites engine buffers: re-running it is harmless) and keeps the fastest."""
         plan.side_decided = True
         capturing = torch.cuda.is_current_stream_capturing()          # (no event synchronisation inside a graph capture)
         if not SIDE_STREAM_WGRAD or SIDE_STREAM_MODE != "auto" or self.grad_ready_cb is not None or capturing:
-            plan.side_on = SIDE_STREAM_WGRAD
+            plan.side_mode = ("all" if SIDE_STREAM_MODE in ("auto", "1") else SIDE_STREAM_MODE) if SIDE_STREAM_WGRAD else "off"
+            if plan.side_mode not in self.SIDE_MODES:
+                plan.side_mode = "all"
         else:
             stream = torch.cuda.current_stream(self.device)
             ms = []
-            for on in (True, False):
-                self._set_side(ops, on)
+            for mode in self.SIDE_MODES:
+                self._set_side(ops, mode)
                 ops.run(self.handle, stream.cuda_stream)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
@@ -928,10 +938,11 @@ class Engine:
                 e1.synchronize()
                 ms.append(e0.elapsed_time(e1) / 3)
             plan.side_ms = tuple(ms)
-            plan.side_on = ms[0] <= ms[1]
+            plan.side_mode = self.SIDE_MODES[min(range(len(ms)), key=lambda k: ms[k])]
+        plan.side_on = plan.side_mode != "off"
         for lst in (plan.bwd, plan.ce["bwd"] if plan.ce else None):
             if lst is not None:
-                self._set_side(lst, plan.side_on)
+                self._set_side(lst, plan.side_mode)
 
     def _run_backward(self, plan: Plan, ops):
         if self.dry_run:
