@@ -29,3 +29,5 @@ prof ${TAG}_labelprop_160x120_b64 --workload labelprop_160x120_b64 --steps 50
 unset RCV_NO_SIDE_STREAM
 cd $GRAFT_REPO_ROOT && bash scripts/pmc_op.sh ${TAG}_conv128 conv 32 30 40 128 128 --mode affine --stats fwd > /dev/null 2>&1
 echo "pmc exit=$?"
+cd $GRAFT_REPO_ROOT && bash scripts/pmc_op.sh ${TAG}_wino128 conv 32 30 40 128 128 --mode affine --stats fwd --wino 1 > /dev/null 2>&1
+echo "pmc wino exit=$?"
