@@ -136,11 +136,18 @@ def dice_weights(weights: Tensor) -> Tensor:
 
 
 def dice_loss(logits: Tensor, target: Tensor, weights: Tensor, eps: float = 1e-7) -> Tensor:
-    """model.py:11-43, multi-class branch (nClass > 1; `weights` already rescaled by dice_weights):
-    1 - mean_c( 2 w_c sum(P_c [t==c]) / (sum(P_c) + #[t==c] + eps) ), P = softmax over channels, sums over (B,H,W)."""
+    """model.py:11-43 (`weights` already rescaled by dice_weights):
+    1 - mean_c( 2 w_c sum(P_c [t==c]) / (sum(P_c) + #[t==c] + eps) ), sums over (B,H,W); multi-class branch (model.py:34-37): P = softmax
+    over channels; single-class branch (model.py:25-33): P = (sigmoid(z), 1 - sigmoid(z)) against the classes (t == 1, t == 0)."""
     C = logits.shape[1]
-    one_hot = F.one_hot(target.long(), C).permute(0, 3, 1, 2).to(logits.dtype)
-    probas = F.softmax(logits, dim=1)
+    if C == 1:
+        hot = F.one_hot(target.long(), 2).permute(0, 3, 1, 2).to(logits.dtype)
+        one_hot = torch.cat([hot[:, 1:2], hot[:, 0:1]], dim=1)
+        pos = torch.sigmoid(logits)
+        probas = torch.cat([pos, 1 - pos], dim=1)
+    else:
+        one_hot = F.one_hot(target.long(), C).permute(0, 3, 1, 2).to(logits.dtype)
+        probas = F.softmax(logits, dim=1)
     dims = (0, 2, 3)
     intersection = torch.sum(probas * one_hot, dims)
     cardinality = torch.sum(probas + one_hot, dims)

@@ -464,8 +464,10 @@ class _DiceFunction(torch.autograd.Function):
 
 
 class DiceLoss(nn.Module):
-    """1 - mean_c(2 w_c I_c / (S_c + N_c + eps)) over softmax probabilities (model.py:5-43, multi-class branch); the
-    class weights are rescaled to mean 1 exactly as model.py:8.  ``last_argmax`` / ``last_stats[2]`` as CrossEntropyLoss2d."""
+    """1 - mean_c(2 w_c I_c / (S_c + N_c + eps)) over softmax probabilities (model.py:5-43); the class weights are rescaled to
+    mean 1 exactly as model.py:8.  ``last_argmax`` / ``last_stats[2]`` as CrossEntropyLoss2d.  The single-class branch (model.py:25-33: one
+    logit channel z, probabilities (sigmoid z, 1 - sigmoid z) against the classes (t == 1, t == 0)) runs on the same kernels: those
+    probabilities are the softmax of (z, 0), so the logits are widened by a zero channel and the target is flipped."""
 
     def __init__(self, weights, eps=1e-7):
         super().__init__()
@@ -477,7 +479,14 @@ class DiceLoss(nn.Module):
 
     def forward(self, logits, true):
         if logits.shape[1] == 1:
-            raise NotImplementedError("the single-class (sigmoid) branch of DiceLoss (model.py:25-33) is not built")
+            if self.weights.numel() not in (1, 2):
+                raise ValueError("single-class DiceLoss takes 1 or 2 class weights (got %d)" % self.weights.numel())
+            if true.dim() == 4:
+                true = true[:, 0]
+            logits = torch.cat([logits, torch.zeros_like(logits)], dim=1)        # softmax((z, 0)) = (sigmoid z, 1 - sigmoid z)
+            true = 1 - true.long()                                               # class 0 <-> target == 1 (model.py:28-30)
+            if self.weights.numel() == 1:
+                self.weights = self.weights.expand(2).clone()
         if logits.shape[1] != self.weights.shape[0]:
             raise ValueError("DiceLoss has %d class weights but the logits have %d channels" % (self.weights.shape[0], logits.shape[1]))
         w = self.weights

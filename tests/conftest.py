@@ -50,6 +50,12 @@ def dv_kats():
 
 
 @pytest.fixture(scope="session")
+def d1_kats():
+    """DiceLoss single-class branch known answers (make_golden.py dice1)."""
+    return np.load(os.path.join(GOLDEN, "dice1.npz"))
+
+
+@pytest.fixture(scope="session")
 def dv_meta():
     with open(os.path.join(GOLDEN, "dice_v2.json")) as f:
         return json.load(f)

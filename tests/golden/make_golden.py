@@ -244,6 +244,26 @@ def whole_net(ref, big=True):
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
+def dice1(ref):
+    """DiceLoss, single-class branch (model.py:25-33): one logit channel, sigmoid, classes (target == 1, target == 0)."""
+    out = {}
+    for name, B, H, W, wts, scale, seed in (("dice1", 2, 24, 32, [1, 3], 1.5, 11), ("dice1_sharp", 1, 16, 48, [2, 1], 8.0, 12)):
+        g = torch.Generator().manual_seed(seed)
+        x = (torch.randn(B, 1, H, W, generator=g) * scale).requires_grad_(True)
+        t = torch.randint(0, 2, (B, H, W), generator=g)
+        w = torch.tensor(wts, dtype=torch.float32)
+        loss = ref.DiceLoss(w)(x, t)
+        loss.backward()
+        x64 = x.detach().double().requires_grad_(True)
+        loss64 = ref.DiceLoss(w.double())(x64, t)
+        loss64.backward()
+        out[name + "/logits"] = npy(x); out[name + "/target"] = npy(t).astype(np.int64); out[name + "/weights"] = npy(w)
+        out[name + "/loss"] = npy(loss); out[name + "/dlogits"] = npy(x.grad)
+        out[name + "/loss64"] = npy(loss64); out[name + "/dlogits64"] = npy(x64.grad)
+        print(name, float(loss), float(loss64))
+    np.savez_compressed(os.path.join(HERE, "dice1.npz"), **out)
+
+
 def dice_v2(ref, big=True):
     """DiceLoss (model.py:5-43) known answers, and whole steps of the v2 net (concat skips, 3x3
     classifier, bellySize 9; train.py:302-307) and of the default net trained with --useDice."""
@@ -461,6 +481,8 @@ if __name__ == "__main__":
         labelprop(ref)
     if "dice_v2" in which:
         dice_v2(ref)
+    if "dice1" in which:        # (not in the default list: added in round 2, the other files stay byte-identical)
+        dice1(ref)
     if "pbfcn" in which:
         pbfcn(ref)
     if "surface" in which:

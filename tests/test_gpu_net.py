@@ -198,6 +198,23 @@ def test_dice_loss_vs_golden(dv_kats, name):
     assert float(crit(lg.detach(), t.unsqueeze(1))) == float(loss)
 
 
+@pytest.mark.parametrize("name", ["dice1", "dice1_sharp"])
+def test_dice_loss_single_class_vs_golden(d1_kats, name):
+    """DiceLoss with ONE logit channel (model.py:25-33, sigmoid branch) on the multi-class kernels (softmax of (z, 0), flipped target)
+    against the reference's own values."""
+    lg = _t(d1_kats[name + "/logits"]).to(DEV).requires_grad_(True)
+    t = _t(d1_kats[name + "/target"]).to(DEV)
+    crit = M.DiceLoss(_t(d1_kats[name + "/weights"])).to(DEV)
+    loss = crit(lg, t)
+    ref, ref64 = float(d1_kats[name + "/loss"]), float(d1_kats[name + "/loss64"])
+    assert abs(float(loss) - ref) <= 1e-5 * abs(ref) or abs(float(loss) - ref64) <= 1e-6 * abs(ref64), (float(loss), ref, ref64)
+    loss.backward()
+    assert lg.grad.shape == lg.shape
+    close(lg.grad, _t(d1_kats[name + "/dlogits64"]).float(), name + " dlogits vs fp64 reference", rtol=1e-4)
+    close(lg.grad, _t(d1_kats[name + "/dlogits"]), name + " dlogits", rtol=1e-3)
+    assert float(crit(lg.detach(), t.unsqueeze(1))) == float(loss)          # [B,1,H,W] targets (model.py:17)
+
+
 def test_step_vs_oracle_on_box():
     """Same seeded inputs through the CPU oracle on this machine (odd batch / non-golden shape)."""
     cfg = O.NetConfig()

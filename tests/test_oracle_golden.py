@@ -101,6 +101,17 @@ def test_dice_loss(dv_kats, name):
     assert torch.equal(lg.grad, _t(dv_kats[name + "/dlogits"]))
 
 
+@pytest.mark.parametrize("name", ["dice1", "dice1_sharp"])
+def test_dice_loss_single_class(d1_kats, name):
+    """model.py:25-33 (one logit channel, sigmoid): the restatement against the reference's own values, bit for bit."""
+    lg = _t(d1_kats[name + "/logits"]).requires_grad_(True)
+    t = _t(d1_kats[name + "/target"])
+    loss = O.dice_loss(lg, t, O.dice_weights(_t(d1_kats[name + "/weights"])))
+    assert torch.equal(loss.detach(), _t(d1_kats[name + "/loss"]))
+    loss.backward()
+    assert torch.equal(lg.grad, _t(d1_kats[name + "/dlogits"]))
+
+
 @pytest.mark.parametrize("tag", SMALL + ["robo_s_4x120x160"] + DICE_V2)
 def test_whole_net_step(golden, tag):
     net_kats, m = golden(tag)
