@@ -215,13 +215,25 @@ def test_dice_loss_single_class_vs_golden(d1_kats, name):
     assert float(crit(lg.detach(), t.unsqueeze(1))) == float(loss)          # [B,1,H,W] targets (model.py:17)
 
 
-def test_step_vs_oracle_on_box():
-    """Same seeded inputs through the CPU oracle on this machine (odd batch / non-golden shape)."""
-    cfg = O.NetConfig()
-    torch.manual_seed(12345678)
-    model = M.ROBO_UNet()
+@pytest.mark.parametrize("ctor,B,H,W,seed", [
+    (dict(), 3, 40, 56, 7),                        # odd batch, non-golden plane
+    (dict(), 1, 16, 16, 8),                        # the smallest plane the four stride-2 levels allow (1 x 1 at the bottom)
+    (dict(), 5, 80, 48, 9),                        # taller than wide
+    (dict(noScale=True), 2, 112, 208, 10),         # the full-resolution (L) net on a plane with ragged tiles everywhere
+    (dict(pool=True), 2, 48, 80, 11),              # U-Net (max-pool) variant
+    (dict(), 7, 32, 144, 12),                      # wide and flat
+])
+@pytest.mark.parametrize("wino", ["auto", "force"])
+def test_step_vs_oracle_on_box(ctor, B, H, W, seed, wino, monkeypatch):
+    """(wino = "force": the Winograd kernel on every stride-1 layer with >= 64 channels, whatever the plane -- odd tile counts, planes
+    smaller than a tile block.)  Same seeded inputs through the CPU oracle on this machine, on shapes no golden covers: the planners (tile shapes, pixel splits,
+    Winograd / direct choice) see planes they were not tuned on; logits, loss, masks and every gradient against the oracle."""
+    import robocupvision_amd.engine as E
+    monkeypatch.setattr(E, "WINOGRAD", wino)
+    cfg = O.NetConfig(**ctor)
+    model = build(ctor)
     st = O.TrainState(model.state_dict(), cfg)
-    x, t = O.synthetic_batch(3, 40, 56, seed=7)
+    x, t = O.synthetic_batch(B, H, W, seed=seed)
     ref = O.train_step(st, x, t, do_step=False)
     res = hip_step(model.to(DEV), x.to(DEV), t.to(DEV), do_step=False)
     close(res["pred"], ref["pred"], "logits vs oracle")
