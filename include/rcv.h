@@ -87,7 +87,10 @@ enum {
   RCV_OP_DICE_BWD    = 24, /* d loss / d logits of the Dice loss                                  */
   RCV_OP_NHWC_TO_NCHW= 25, /* out[n][c][p] = in[n][p][c] + bias[c], c < cout <= cin (3x3 classifier tail) */
   RCV_OP_NCHW_TO_NHWC= 26, /* out[n][p][c] = c < cin ? in[n][c][p] : 0, cout channels per pixel     */
-  RCV_OP_SGD         = 27  /* torch.optim.SGD(momentum, weight_decay) over a flat buffer (trainer.py:176-178) */
+  RCV_OP_SGD         = 27, /* torch.optim.SGD(momentum, weight_decay) over a flat buffer (trainer.py:176-178) */
+  RCV_OP_NOP         = 28, /* nothing is launched (a slot of an op list whose work was folded into a later record)       */
+  RCV_OP_WGRAD_REDUCE_BATCH = 29 /* RCV_OP_WGRAD_REDUCE of several layers in ONE launch: p[RCV_P_IN] -> rcv_reduce_job[i[RCV_I_COUNT]]
+                                   * (device memory); same fixed summation order per layer as the single form                  */
 };
 
 /* how an operand is produced from memory while it is staged (rcv_op.i[RCV_I_INMODE] etc.) */
@@ -219,6 +222,17 @@ typedef struct rcv_pack_job {
                            * 2: Winograd layout [16][rows][cols] = G g G^T (see conv_wino.hip)                                  */
   int32_t reserved;
 } rcv_pack_job;
+
+/* One row of the RCV_OP_WGRAD_REDUCE_BATCH job table: the arguments of one RCV_OP_WGRAD_REDUCE record. `first_block` = number of
+ * 64-element blocks of the jobs before this one (job j owns blocks [first_block_j, first_block_{j+1}); a block sums 64 consecutive
+ * elements of the partial layout [9][CBP][CAP] (+ the bias row): blocks_j = ceil((9*CBP*CAP + (db ? CBP : 0)) / 64), with
+ * CAP = CA <= 4 ? 4 : round16(CA), CBP = round16(CB)); i[RCV_I_NPART] of the record = total number of blocks. */
+typedef struct rcv_reduce_job {
+  const float* part;  /* [nsplit][9][CBP][CAP] then, if db, [nsplit][CBP]                          */
+  float*       dw;    /* [CB][CA][3][3]                                                            */
+  float*       db;    /* [CB] or NULL                                                              */
+  int32_t nsplit, CB, CA, first_block;
+} rcv_reduce_job;
 
 /* ------------------------------------------------------------------------------------------ */
 /* Named entry points (each = fill one record + rcv_run).  Reference call sites they replace:  */

@@ -19,7 +19,8 @@ RCV_P__N = 20
 
 (OP_CONV, OP_TCONV, OP_WGRAD, OP_WGRAD_REDUCE, OP_PACK, OP_BN_FINALIZE, OP_BN_EVAL, OP_BN_BWD, OP_COMBINE, OP_CLS_FWD,
  OP_CLS_BWD, OP_CE_FWD, OP_CE_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_ADAM_L1, OP_MEMSET, OP_CONV1X1, OP_ADD_SLICE,
- OP_MATERIALIZE, OP_BWD_STATS, OP_CONFUSION, OP_DICE_FWD, OP_DICE_BWD, OP_NHWC_TO_NCHW, OP_NCHW_TO_NHWC, OP_SGD) = range(1, 28)
+ OP_MATERIALIZE, OP_BWD_STATS, OP_CONFUSION, OP_DICE_FWD, OP_DICE_BWD, OP_NHWC_TO_NCHW, OP_NCHW_TO_NHWC, OP_SGD, OP_NOP,
+ OP_WGRAD_REDUCE_BATCH) = range(1, 30)
 
 LOAD_PLAIN, LOAD_AFFINE, LOAD_GRAD_ENC, LOAD_GRAD_DEC, LOAD_NCHW, LOAD_AFFINE_RELU = range(6)
 STATS_NONE, STATS_FWD, STATS_BWD_ENC, STATS_BWD_DEC = range(4)
@@ -38,6 +39,11 @@ class RcvPackJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("D0", C.c_int32), ("D1", C.c_int32),
                 ("rows_from_d1", C.c_int32), ("flip", C.c_int32), ("rows_pad", C.c_int32), ("cols_pad", C.c_int32),
                 ("merged", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RcvReduceJob(C.Structure):      # struct rcv_reduce_job of include/rcv.h
+    _fields_ = [("part", C.c_void_p), ("dw", C.c_void_p), ("db", C.c_void_p), ("nsplit", C.c_int32), ("CB", C.c_int32),
+                ("CA", C.c_int32), ("first_block", C.c_int32)]
 
 
 EXPORTS = [

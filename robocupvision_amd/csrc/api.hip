@@ -102,7 +102,11 @@ static int dispatch(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
       return rcv_launch_conv(h, op, s, q);
     case RCV_OP_WGRAD:
     case RCV_OP_WGRAD_REDUCE:
+    case RCV_OP_WGRAD_REDUCE_BATCH:
       return rcv_launch_wgrad(h, op, s, q);
+    case RCV_OP_NOP:
+      if (q) { snprintf(q->label, sizeof(q->label), "nop"); q->n_part = 0; q->n_split = 0; q->part_bytes = 0; }
+      return RCV_OK;
     default:
       return rcv_launch_small(h, op, s, q);
   }
@@ -148,6 +152,7 @@ static int run_ops(rcv_handle* h, const rcv_op* ops, int n, void* stream, bool j
   // stream-ordered call.  No host synchronisation; capturable (the side stream joins the capture through the events).
   bool prev_side = false, side_used = false;
   for (int k = 0; k < n; ++k) {
+    if (ops[k].kind == RCV_OP_NOP) continue;    // (does not end a run of side-stream ops either: no extra fork around an empty slot)
     const bool side = (ops[k].flags & RCV_F_SIDE_STREAM) != 0;
     if (side && !h->side_stream) {
       RCV_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));

@@ -360,15 +360,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
 }
 
 // dW[cb][ca][tap] = sum_split part[split][tap][cb][ca];  db[cb] = sum_split part_bias[split][cb]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_bias,
-                                                           float* __restrict__ dw, float* __restrict__ db, int nsplit, int CB, int CA,
-                                                           int CBP, int CAP) {
-  // 64 consecutive partial-layout elements x 4 split groups per workgroup; every thread keeps 4 loads in
-  // flight; the order of additions is a fixed function of (nsplit) => bitwise reproducible.
-  __shared__ double sh[4][64];
+// 64 consecutive partial-layout elements x 4 split groups per workgroup (block `blk` of this layer); every thread keeps 4 loads in
+// flight; the order of additions is a fixed function of (nsplit) => bitwise reproducible.
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ part, const float* __restrict__ part_bias, float* __restrict__ dw,
+                                                   float* __restrict__ db, int nsplit, int CB, int CA, int CBP, int CAP, int blk,
+                                                   double (&sh)[4][64]) {
   const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int totalP = 9 * CBP * CAP;
-  const int e = blockIdx.x * 64 + el;
+  const int e = blk * 64 + el;
   const size_t stride = (size_t)totalP;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;     // double: bias / BN-adjacent filters are cancellation-heavy sums
   const float* src = nullptr;
@@ -397,6 +396,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       if (db && cb < CB) db[cb] = u;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_bias,
+                                                           float* __restrict__ dw, float* __restrict__ db, int nsplit, int CB, int CA,
+                                                           int CBP, int CAP) {
+  __shared__ double sh[4][64];
+  wgrad_reduce_block(part, part_bias, dw, db, nsplit, CB, CA, CBP, CAP, blockIdx.x, sh);
+}
+
+// several layers in one launch (RCV_OP_WGRAD_REDUCE_BATCH): the workgroup finds its job in the (<= 64 rows) table
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const rcv_reduce_job* __restrict__ jobs, int njobs) {
+  __shared__ double sh[4][64];
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
+  const rcv_reduce_job jb = jobs[j];
+  const int CAP = jb.CA <= 4 ? 4 : (jb.CA + 15) / 16 * 16, CBP = (jb.CB + 15) / 16 * 16;      // wgrad_cap / round_up of the host side
+  const float* pb = jb.db ? jb.part + (size_t)jb.nsplit * 9 * CBP * CAP : nullptr;
+  wgrad_reduce_block(jb.part, pb, jb.dw, jb.db, jb.nsplit, jb.CB, jb.CA, CBP, CAP, (int)blockIdx.x - jb.first_block, sh);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -574,6 +591,14 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
 }
 
 int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query) {
+  if (op->kind == RCV_OP_WGRAD_REDUCE_BATCH) {
+    if (query) { snprintf(query->label, sizeof(query->label), "wgrad_reduce_batch"); query->n_part = 0; query->n_split = 0; query->part_bytes = 0; return RCV_OK; }
+    const int njobs = op->i[RCV_I_COUNT], blocks = op->i[RCV_I_NPART];
+    RCV_CHECK_ARG(op->p[RCV_P_IN] && njobs >= 1 && njobs <= 64 && blocks >= 1, "wgrad_reduce_batch: needs a job table (1..64 rows) and the block count");
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, s, (const rcv_reduce_job*)op->p[RCV_P_IN], njobs);
+    RCV_HIP(hipGetLastError());
+    return RCV_OK;
+  }
   if (op->kind == RCV_OP_WGRAD_REDUCE) {
     if (query) { snprintf(query->label, sizeof(query->label), "wgrad_reduce"); query->n_part = 0; query->n_split = 0; query->part_bytes = 0; return RCV_OK; }
     const int CA = op->i[RCV_I_CIN], CB = op->i[RCV_I_COUT], nsplit = op->i[RCV_I_NSPLIT];

@@ -34,6 +34,10 @@ SIDE_STREAM_WGRAD = not os.environ.get("RCV_NO_SIDE_STREAM")
 # the caller's stream ("off") -- and keeps the fastest; "1" / "all" / "reduce" / "off": that schedule, no measurement.
 SIDE_STREAM_MODE = os.environ.get("RCV_SIDE_STREAM", "auto")
 FUSE_UP_INTO_CLS = not os.environ.get("RCV_NO_FUSED_UP")
+# Filter-gradient reductions per batched launch (RCV_OP_WGRAD_REDUCE_BATCH): the reductions of up to this many consecutive layers of the
+# backward list run as ONE launch at the position of the last of them (18 launches at the ~5 us floor of a dependent launch -> 3).
+# 0 / 1: one launch per layer.
+REDUCE_BATCH = int(os.environ.get("RCV_REDUCE_BATCH", "6"))
 CLS3_PAD = 8                    # class channels of the 3x3 classifier (v2) are padded to this many NHWC channels
 MERGED_TCONV_MAX_COUT = 16      # transposed convs with at most this many output channels use the merged-parity kernel
 # Winograd F(2x2,3x3) for the wide stride-1 convs (conv_wino.hip): "auto" = where the library asks for it (>= 64 channels and a grid that
@@ -175,6 +179,7 @@ class Plan:
         self.n_head = 0                      # leading ops of fwd that depend on the parameters only (filter repack, eval-mode BN constants)
         self.head_key = None                 # parameter-state key the head was last run for (eval plans)
         self.bwd_marks: List = []            # [(ops executed, lowest final flat-gradient offset)]
+        self.reduce_outputs: Dict = {}       # index of a batched reduction launch -> gradient pointers it produces
         self.ce = None                       # lazily built op lists with the cross entropy fused into the classifier ops
         self.side_decided = False            # filter gradients on the second stream: measured on the first backward pass
         self.side_on = True
@@ -694,11 +699,45 @@ class Engine:
                         grad_target(src, dop, src.H, src.W)
                         bwd.append(dop)
 
+        # ---- batched filter-gradient reductions: the records keep their positions (every index into the list stays valid); all but
+        # the last reduction of a group become RCV_OP_NOP, the last one becomes the table-driven launch of the whole group ----
+        batch_at: Dict[int, int] = {}          # index of a folded reduction -> index of the launch that now carries it
+        plan.reduce_outputs = {}               # index of a batched launch -> [gradient pointers it produces] (schedule tests)
+        if training and REDUCE_BATCH > 1:
+            idxs = [k for k, op in enumerate(bwd) if op.kind == L.OP_WGRAD_REDUCE]
+            for g0 in range(0, len(idxs), REDUCE_BATCH):
+                grp = idxs[g0:g0 + REDUCE_BATCH]
+                if len(grp) < 2:
+                    continue
+                rjobs, first, kib, outs = [], 0, 0.0, []
+                for k in grp:
+                    op = bwd[k]
+                    ca, cb, ns = op.i[L.RCV_I_CIN], op.i[L.RCV_I_COUT], op.i[L.RCV_I_NSPLIT]
+                    cap, cbp = (4 if ca <= 4 else _round_up(ca, 16)), _round_up(cb, 16)
+                    db = op.p[L.RCV_P_BIAS] or None
+                    rjobs.append(L.RcvReduceJob(part=op.p[L.RCV_P_PART], dw=op.p[L.RCV_P_OUT], db=db, nsplit=ns, CB=cb, CA=ca, first_block=first))
+                    first += -(-(9 * cbp * cap + (cbp if db else 0)) // 64)
+                    kib += self.op_work(op)[1] / 1024.0
+                    outs += [q for q in (op.p[L.RCV_P_OUT], db) if q]
+                table = (L.RcvReduceJob * len(rjobs))(*rjobs)
+                dev_table = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
+                plan.keep.append(dev_table)
+                for k in grp[:-1]:
+                    bwd[k] = L.make_op(L.OP_NOP, 0)
+                    batch_at[k] = grp[-1]
+                bwd[grp[-1]] = L.make_op(L.OP_WGRAD_REDUCE_BATCH, 0, count=len(rjobs), npart=first, aux0=int(kib), p_in=dev_table.data_ptr())
+                batch_at[grp[-1]] = grp[-1]
+                plan.reduce_outputs[grp[-1]] = outs
+
         # gradient-ready marks: after bwd ops [0:end) every parameter at flat offset >= lo is final (parameters are laid
         # out in forward order and backward visits the nodes in reverse, so the finished region is a growing suffix)
-        marks, lo = [], fl.numel
+        marks, lo, prev_end = [], fl.numel, 0
         for k, (start, node) in enumerate(plan.bwd_marks):
             end = plan.bwd_marks[k + 1][0] if k + 1 < len(plan.bwd_marks) else len(bwd)
+            for q in range(start, end):            # a node whose reduction was folded into a later launch is final only behind that launch
+                if q in batch_at:
+                    end = max(end, batch_at[q] + 1)
+            end = prev_end = max(end, prev_end)
             offs = [fl.offsets[fl.index(q)] for q in node_params(node)] if training else []
             if offs:
                 lo = min(lo, min(offs))
@@ -728,7 +767,7 @@ class Engine:
         # second HIP stream inside rcv_run (measured -4 % step time: their latency-bound phases fill the other kernels' gaps)
         if SIDE_STREAM_WGRAD:
             for op in bwd:
-                if op.kind in (L.OP_WGRAD, L.OP_WGRAD_REDUCE, L.OP_MEMSET):
+                if op.kind in (L.OP_WGRAD, L.OP_WGRAD_REDUCE, L.OP_WGRAD_REDUCE_BATCH, L.OP_MEMSET):
                     op.flags |= L.F_SIDE_STREAM
         plan.fwd = L.OpList(fwd)
         plan.bwd = L.OpList(bwd)
@@ -816,6 +855,8 @@ class Engine:
             nbytes = 4.0 * (px * cin * two(i[L.RCV_I_INMODE]) + n * ho * wo * cout * two(i[L.RCV_I_INMODE2]))
         elif k == L.OP_WGRAD_REDUCE:
             nbytes = 4.0 * i[L.RCV_I_NSPLIT] * (9 * _round_up(cout, 16) * max(_round_up(cin, 4), 4)) + 4.0 * 9 * cin * cout
+        elif k == L.OP_WGRAD_REDUCE_BATCH:
+            nbytes = 1024.0 * i[L.RCV_I_AUX0]          # the folded reductions' bytes (set when the group was built)
         elif k in (L.OP_BN_FINALIZE, L.OP_BN_BWD):
             nbytes = 4.0 * i[L.RCV_I_NPART] * 2 * cout
         elif k == L.OP_CLS_FWD:
@@ -912,7 +953,7 @@ class Engine:
         mode = {True: "all", False: "off"}.get(mode, mode)
         for k in range(ops.n):
             op = ops.arr[k]
-            if op.kind in (L.OP_WGRAD, L.OP_WGRAD_REDUCE, L.OP_MEMSET):
+            if op.kind in (L.OP_WGRAD, L.OP_WGRAD_REDUCE, L.OP_WGRAD_REDUCE_BATCH, L.OP_MEMSET):
                 on = mode == "all" or (mode == "reduce" and op.kind != L.OP_WGRAD)
                 op.flags = (op.flags | L.F_SIDE_STREAM) if on else (op.flags & ~L.F_SIDE_STREAM)
 

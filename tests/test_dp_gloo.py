@@ -25,8 +25,9 @@ if ROOT not in sys.path:
 class SimulatedOps:
     """Stands in for _lib.OpList: 'running' ops [a, b) makes the gradients those ops produce appear in flat.grad."""
 
-    def __init__(self, oplist, flat, grads, L):
+    def __init__(self, oplist, flat, grads, L, batch_outputs=None):
         self.arr, self.n, self.flat, self.grads, self.L = oplist.arr, oplist.n, flat, grads, L
+        self.batch_outputs = batch_outputs or {}        # Plan.reduce_outputs: index of a batched reduction -> gradient pointers it writes
         base = flat.grad.data_ptr()
         self.addr2k = {base + 4 * off: k for k, off in enumerate(flat.offsets)}
         self.produced = set()
@@ -39,8 +40,11 @@ class SimulatedOps:
         self.slices.append((a, b, join))
         for i in range(a, b):
             op = self.arr[i]
-            for slot in slots.get(op.kind, ()):
-                k = self.addr2k.get(op.p[slot] or 0)
+            ptrs = [op.p[slot] or 0 for slot in slots.get(op.kind, ())]
+            if op.kind == L.OP_WGRAD_REDUCE_BATCH:
+                ptrs = list(self.batch_outputs[i])
+            for ptr in ptrs:
+                k = self.addr2k.get(ptr)
                 if k is None:
                     continue
                 view = self.flat.grad_view(k)
@@ -102,7 +106,7 @@ def _exchange_pass(L, eng, plan, ops_list, grads, all_reduce, overlap=True):
     fl.grad.zero_()
     for k in range(len(fl.params)):
         fl.grad_view(k).fill_(float("nan"))        # poison: a range exchanged before its producer ran stays NaN
-    sim = SimulatedOps(ops_list, fl, grads, L)
+    sim = SimulatedOps(ops_list, fl, grads, L, plan.reduce_outputs)
     log = []
     exch = GradExchange(eng, RecordingStreams(log, overlap), lambda t: (log.append(("all_reduce", t.numel())), all_reduce(t))[1],
                         join_side=lambda h, s: log.append(("join_side", s)))
