@@ -226,7 +226,8 @@ typedef struct rcv_pack_job {
 /* One row of the RCV_OP_WGRAD_REDUCE_BATCH job table: the arguments of one RCV_OP_WGRAD_REDUCE record. `first_block` = number of
  * 64-element blocks of the jobs before this one (job j owns blocks [first_block_j, first_block_{j+1}); a block sums 64 consecutive
  * elements of the partial layout [9][CBP][CAP] (+ the bias row): blocks_j = ceil((9*CBP*CAP + (db ? CBP : 0)) / 64), with
- * CAP = CA <= 4 ? 4 : round16(CA), CBP = round16(CB)); i[RCV_I_NPART] of the record = total number of blocks. */
+ * CAP = CA <= 4 ? 4 : round16(CA), CBP = round16(CB)); i[RCV_I_NPART] of the record = total number of blocks.
+ * nsplit == 0: a zero-fill job, db[0..CB) = 0 in ceil(CB / 256) blocks (the RCV_OP_MEMSET of a bias gradient, folded in). */
 typedef struct rcv_reduce_job {
   const float* part;  /* [nsplit][9][CBP][CAP] then, if db, [nsplit][CBP]                          */
   float*       dw;    /* [CB][CA][3][3]                                                            */

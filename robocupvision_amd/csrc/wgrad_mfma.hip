@@ -411,6 +411,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const rcv_reduc
   int j = 0;
   while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
   const rcv_reduce_job jb = jobs[j];
+  if (jb.nsplit == 0) {      // zero-fill job: db[0..CB) = 0 (the bias ahead of a BatchNorm has an identically zero gradient)
+    const int e = ((int)blockIdx.x - jb.first_block) * 256 + (int)threadIdx.x;
+    if (e < jb.CB) jb.db[e] = 0.f;
+    return;
+  }
   const int CAP = jb.CA <= 4 ? 4 : (jb.CA + 15) / 16 * 16, CBP = (jb.CB + 15) / 16 * 16;      // wgrad_cap / round_up of the host side
   const float* pb = jb.db ? jb.part + (size_t)jb.nsplit * 9 * CBP * CAP : nullptr;
   wgrad_reduce_block(jb.part, pb, jb.dw, jb.db, jb.nsplit, jb.CB, jb.CA, CBP, CAP, (int)blockIdx.x - jb.first_block, sh);

@@ -702,23 +702,31 @@ class Engine:
         # ---- batched filter-gradient reductions: the records keep their positions (every index into the list stays valid); all but
         # the last reduction of a group become RCV_OP_NOP, the last one becomes the table-driven launch of the whole group ----
         batch_at: Dict[int, int] = {}          # index of a folded reduction -> index of the launch that now carries it
-        plan.reduce_outputs = {}               # index of a batched launch -> [gradient pointers it produces] (schedule tests)
+        plan.reduce_outputs = {}               # index of a batched launch -> [(gradient pointer it writes, zero-fill?)] (schedule tests)
         if training and REDUCE_BATCH > 1:
             idxs = [k for k, op in enumerate(bwd) if op.kind == L.OP_WGRAD_REDUCE]
             for g0 in range(0, len(idxs), REDUCE_BATCH):
                 grp = idxs[g0:g0 + REDUCE_BATCH]
                 if len(grp) < 2:
                     continue
+                # the bias-gradient memsets between the group's first and last reduction ride along as zero-fill jobs
+                grp = sorted(grp + [k for k in range(grp[0], grp[-1]) if bwd[k].kind == L.OP_MEMSET])
                 rjobs, first, kib, outs = [], 0, 0.0, []
                 for k in grp:
                     op = bwd[k]
+                    if op.kind == L.OP_MEMSET:
+                        cnt = op.i[L.RCV_I_COUNT]
+                        rjobs.append(L.RcvReduceJob(part=None, dw=None, db=op.p[L.RCV_P_OUT], nsplit=0, CB=cnt, CA=0, first_block=first))
+                        first += -(-cnt // 256)
+                        outs.append((op.p[L.RCV_P_OUT], True))
+                        continue
                     ca, cb, ns = op.i[L.RCV_I_CIN], op.i[L.RCV_I_COUT], op.i[L.RCV_I_NSPLIT]
                     cap, cbp = (4 if ca <= 4 else _round_up(ca, 16)), _round_up(cb, 16)
                     db = op.p[L.RCV_P_BIAS] or None
                     rjobs.append(L.RcvReduceJob(part=op.p[L.RCV_P_PART], dw=op.p[L.RCV_P_OUT], db=db, nsplit=ns, CB=cb, CA=ca, first_block=first))
                     first += -(-(9 * cbp * cap + (cbp if db else 0)) // 64)
                     kib += self.op_work(op)[1] / 1024.0
-                    outs += [q for q in (op.p[L.RCV_P_OUT], db) if q]
+                    outs += [(q, False) for q in (op.p[L.RCV_P_OUT], db) if q]
                 table = (L.RcvReduceJob * len(rjobs))(*rjobs)
                 dev_table = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
                 plan.keep.append(dev_table)

@@ -27,7 +27,7 @@ class SimulatedOps:
 
     def __init__(self, oplist, flat, grads, L, batch_outputs=None):
         self.arr, self.n, self.flat, self.grads, self.L = oplist.arr, oplist.n, flat, grads, L
-        self.batch_outputs = batch_outputs or {}        # Plan.reduce_outputs: index of a batched reduction -> gradient pointers it writes
+        self.batch_outputs = batch_outputs or {}        # Plan.reduce_outputs: index of a batched reduction -> [(gradient pointer, zero-fill?)]
         base = flat.grad.data_ptr()
         self.addr2k = {base + 4 * off: k for k, off in enumerate(flat.offsets)}
         self.produced = set()
@@ -40,15 +40,15 @@ class SimulatedOps:
         self.slices.append((a, b, join))
         for i in range(a, b):
             op = self.arr[i]
-            ptrs = [op.p[slot] or 0 for slot in slots.get(op.kind, ())]
+            outs = [(op.p[slot] or 0, op.kind == L.OP_MEMSET) for slot in slots.get(op.kind, ())]
             if op.kind == L.OP_WGRAD_REDUCE_BATCH:
-                ptrs = list(self.batch_outputs[i])
-            for ptr in ptrs:
+                outs = list(self.batch_outputs[i])
+            for ptr, zero in outs:
                 k = self.addr2k.get(ptr)
                 if k is None:
                     continue
                 view = self.flat.grad_view(k)
-                if op.kind == L.OP_MEMSET:
+                if zero:
                     view.zero_()                # bias ahead of a BatchNorm: exactly zero in the engine
                 else:
                     view.copy_(self.grads[k])
