@@ -476,8 +476,9 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   if (nchw) RCV_CHECK_ARG(CA <= 4, "wgrad: NCHW gathered operand supports <=4 channels");
   else RCV_CHECK_ARG(CA % 4 == 0, "wgrad: gathered channels %d must be a multiple of 4", CA);
   pl->CAP = wgrad_cap(CA); pl->CBP = round_up(CB, 16);
-  const int cbt_want = pl->CBP >= 64 ? 64 : (pl->CBP >= 32 ? 32 : 16);
-  const int cat_want = pl->CAP >= 64 ? 64 : (pl->CAP >= 32 ? 32 : 16);
+  int cbt_want = pl->CBP >= 64 ? 64 : (pl->CBP >= 32 ? 32 : 16);
+  int cat_want = pl->CAP >= 64 ? 64 : (pl->CAP >= 32 ? 32 : 16);
+  if (const char* ev = RCV_ENV("RCV_WGRAD_CT")) { const int c = atoi(ev); if (c == 16 || c == 32) { if (cbt_want > c) cbt_want = c; if (cat_want > c) cat_want = c; } }
   pl->tile = -1;
   pl->first = 0;
   if (wgrad_first_supported(op)) {      // first layer: vector-ALU kernel (wgrad_first.hip), one partial row per persistent workgroup
