@@ -104,7 +104,7 @@ def _host_threads():
     return min(threads, 16)      # the share of host cores a 1-GPU slot of the box owns (oversubscribing 256 throttles)
 
 
-def cpu_baseline(ctor, H, W, budget_s=20.0, dice=False):
+def cpu_baseline(ctor, H, W, budget_s=15.0, dice=False):
     """The CPU oracle on this host: same step body, all host threads, bounded sample."""
     from oracle import cpu_reference as O
     threads = _host_threads()
@@ -125,7 +125,7 @@ def cpu_baseline(ctor, H, W, budget_s=20.0, dice=False):
             O.train_step(st, x, t)
             n += 1
             el = time.perf_counter() - t0
-            if el > budget_s or n >= 20:
+            if el > budget_s or (n >= 20 and el >= 10.0):      # 10-15 s of CPU work
                 break
         return {"value": round(B * n / el, 3), "unit": "img/s", "cores": threads, "kind": "port",
                 "sample": "%d steps of batch %d at %dx%d, torch %s CPU, %d threads" % (n, B, W, H, torch.__version__, threads)}
