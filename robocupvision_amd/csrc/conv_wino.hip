@@ -1,4 +1,4 @@
-// Wide 3x3 stride-1 convolutions (>= 64 channels in and out) by Winograd F(2x2, 3x3) on the gfx950 fp32 matrix cores.
+// Wide 3x3 stride-1 convolutions (>= 64 output channels, >= 32 input channels) by Winograd F(2x2, 3x3) on the gfx950 fp32 matrix cores.
 //
 //   Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, 4x4 input patch d, 3x3 filter g
 //
@@ -355,7 +355,7 @@ bool conv_wino_supported(const rcv_handle* h, const rcv_op* op, int kind) {
 bool conv_wino_wanted(const rcv_handle* h, const rcv_op* op, bool force) {
   const int N = op->i[RCV_I_N], H = op->i[RCV_I_H], W = op->i[RCV_I_W], Cin = op->i[RCV_I_CIN], Cout = op->i[RCV_I_COUT];
   if (op->kind != RCV_OP_CONV || op->i[RCV_I_STRIDE] != 1 || op->i[RCV_I_DIL] != 1) return false;
-  if (op->i[RCV_I_INMODE] == RCV_LOAD_NCHW || Cin % 16 || Cin < 64 || Cout % 4 || Cout < 64) return false;
+  if (op->i[RCV_I_INMODE] == RCV_LOAD_NCHW || Cin % 16 || Cin < 32 || Cout % 4 || Cout < 64) return false;     // (32 and 48 input channels: measured 20-26 % faster than the direct kernel)
   if ((long long)N * H * W * Cin >= (1ll << 31)) return false;
   if (force) return true;
   ConvPlan pl;

@@ -40,7 +40,7 @@ FUSE_UP_INTO_CLS = not os.environ.get("RCV_NO_FUSED_UP")
 REDUCE_BATCH = min(int(os.environ.get("RCV_REDUCE_BATCH", "6")), 24)      # (the job table of one launch holds at most 64 rows)
 CLS3_PAD = 8                    # class channels of the 3x3 classifier (v2) are padded to this many NHWC channels
 MERGED_TCONV_MAX_COUT = 16      # transposed convs with at most this many output channels use the merged-parity kernel
-# Winograd F(2x2,3x3) for the wide stride-1 convs (conv_wino.hip): "auto" = where the library asks for it (>= 64 channels and a grid that
+# Winograd F(2x2,3x3) for the wide stride-1 convs (conv_wino.hip): "auto" = where the library asks for it (>= 64 output and >= 32 input channels and a grid that
 # covers the chip), "force" = wherever the kernel can run (tests), "off" = never
 WINOGRAD = os.environ.get("RCV_WINOGRAD", "auto")
 
