@@ -247,6 +247,23 @@ def test_step_vs_oracle_on_box(ctor, B, H, W, seed, wino, monkeypatch):
         close(res["grads"][n], st.sd[n].grad, "grad %s vs oracle" % n, rtol=1e-3, floor=1.0)
 
 
+def test_outputs_are_fresh_tensors(monkeypatch):
+    """As in the reference, a prediction kept across iterations stays what it was (the module surface returns a copy of the engine's
+    buffer); model.ALIAS_OUTPUTS = True hands out the engine's buffer itself, which the next forward of the same shape overwrites."""
+    model = build(dict(noScale=False)).to(DEV).eval()
+    xa, _ = O.synthetic_batch(2, 48, 64, seed=1)
+    xb, _ = O.synthetic_batch(2, 48, 64, seed=2)
+    with torch.no_grad():
+        pa = model(xa.to(DEV))
+        keep = pa.clone()
+        pb = model(xb.to(DEV))
+        assert pa.data_ptr() != pb.data_ptr() and torch.equal(pa, keep) and not torch.equal(pa, pb)
+        monkeypatch.setattr(M, "ALIAS_OUTPUTS", True)
+        qa = model(xa.to(DEV))
+        qb = model(xb.to(DEV))
+        assert qa.data_ptr() == qb.data_ptr() and torch.equal(qb, pb)
+
+
 def test_determinism_bitwise():
     """No float atomics anywhere: two runs of the same step give bit-identical logits and gradients."""
     x, t = O.synthetic_batch(2, 48, 64)
