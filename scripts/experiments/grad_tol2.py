@@ -1,0 +1,26 @@
+"""Per-channel view of the worst BN-affine gradient of grad_tol.py: HIP vs the oracle in fp32 and fp64 (CPU, this box)."""
+import os, sys, json
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_net as T
+from oracle import cpu_reference as O
+ctor = dict(noScale=False, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128)
+B, H, W = 4, 120, 160
+x, t = O.synthetic_batch(B, H, W)
+model = T.build(ctor)
+sd = model.state_dict()
+st32 = O.TrainState({k: v.clone() for k, v in sd.items()}, O.NetConfig(**ctor))
+O.train_step(st32, x, t, do_step=False)
+st64 = O.TrainState({k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}, O.NetConfig(**ctor))
+st64.ce_weight = st64.ce_weight.double() if st64.ce_weight is not None else None
+O.train_step(st64, x.double(), t, do_step=False)
+res = T.hip_step(model.to(T.DEV), x.to(T.DEV), t.to(T.DEV), do_step=False)
+for key in ["downPart.Level1.layers.Conv0.bn.weight", "downPart.Level1.layers.Conv0.bn.bias", "downPart.Level1.layers.Conv0.conv.weight",
+            "downPart.Level0.layers.Conv0.bn.weight", "downPart.Level2.layers.Conv0.bn.weight", "upPart.1.bn.weight", "upPart.0.bn.weight"]:
+    if key not in st64.sd: continue
+    g64 = st64.sd[key].grad.double().reshape(-1); g32 = st32.sd[key].grad.double().reshape(-1); gh = res["grads"][key].double().cpu().reshape(-1)
+    sc = g64.abs().max()
+    print("%-44s |g64|max %.3e  oracle32 max err %.2e  hip max err %.2e   (norm dev: oracle32 %.2e hip %.2e)" %
+          (key, sc, float((g32 - g64).abs().max() / sc), float((gh - g64).abs().max() / sc),
+           abs(float(g32.norm() - g64.norm())) / float(g64.norm()), abs(float(gh.norm() - g64.norm())) / float(g64.norm())))
