@@ -1,0 +1,112 @@
+"""Kernel-level accuracy through the C ABI against PyTorch CPU in float64: one op record (+ its pack / reduce) per case, plain operands
+and the load transforms of the step (BatchNorm apply, BatchNorm + ReLU backward), on planes that are large, tiny and ragged.
+
+Bars (max error relative to the largest entry of the fp64 result): convolutions 3e-6 (direct) / 2e-6 (Winograd), filter gradients 5e-7,
+bias gradients 5e-7.  Measured (scripts/experiments/conv_check.py, wgrad_check.py): <= 1.1e-6, <= 4.9e-7, <= 1.7e-7, <= 1.5e-7."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _rand(gen, *shape, scale=1.0):
+    return torch.randn(*shape, generator=gen) * scale
+
+
+def _load_fp64(mode, x, aux, c, L):
+    X, A, C = x.double(), aux.double(), c.double()
+    if mode == L.LOAD_GRAD_ENC:        # rcv.h: v = aux > 0 ? c0*x + c1 + c2*aux : 0
+        return torch.where(A > 0, C[0] * X + C[1] + C[2] * A, torch.zeros((), dtype=torch.float64))
+    if mode == L.LOAD_AFFINE:          # v = x*c0 + c1
+        return X * C[0] + C[1]
+    return X
+
+
+CONV_SHAPES = [(4, 15, 20, 64, 64, 1), (4, 15, 20, 128, 64, 1), (2, 30, 40, 128, 128, 1), (4, 30, 40, 64, 32, 1), (4, 15, 20, 64, 128, 1),
+               (4, 30, 40, 32, 64, 2), (4, 30, 40, 32, 32, 1), (4, 60, 80, 16, 16, 1), (3, 5, 7, 64, 64, 1), (2, 37, 53, 32, 64, 1),
+               (2, 120, 160, 8, 16, 2), (5, 9, 11, 128, 128, 1), (1, 60, 80, 64, 128, 2), (2, 48, 64, 16, 32, 2)]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,s", CONV_SHAPES)
+@pytest.mark.parametrize("mode_name", ["grad_enc", "affine"])
+def test_conv_kernels_vs_fp64(N, H, W, Cin, Cout, s, mode_name):
+    from robocupvision_amd import _lib as L
+    h = L.handle(0)
+    mode = {"grad_enc": L.LOAD_GRAD_ENC, "affine": L.LOAD_AFFINE}[mode_name]
+    gen = torch.Generator().manual_seed(1000 + H * W + Cin)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    x, xa, c = _rand(gen, N, H, W, Cin), _rand(gen, N, H, W, Cin), _rand(gen, 5, Cin, scale=0.5)
+    w, resid = _rand(gen, Cout, Cin, 3, 3, scale=0.1), _rand(gen, N, Ho, Wo, Cout)
+    ref = F.conv2d(_load_fp64(mode, x, xa, c, L).permute(0, 3, 1, 2), w.double(), stride=s, padding=1).permute(0, 2, 3, 1) + resid.double()
+    xd, xad, cd, wd, rd = (v.to(DEV) for v in (x, xa, c, w, resid))
+    winos = [0] + ([1] if (s == 1 and Cin % 16 == 0 and Cin >= 32 and Cout >= 64) else [])
+    for wino in winos:
+        rp, cp = (Cin + 3) // 4 * 4, (Cout + 15) // 16 * 16
+        wp = torch.zeros((16 if wino else 9) * rp * cp, device=DEV)
+        job = L.RcvPackJob()
+        job.src, job.dst, job.D0, job.D1 = wd.data_ptr(), wp.data_ptr(), Cout, Cin
+        job.rows_from_d1, job.flip, job.rows_pad, job.cols_pad, job.merged = 1, 0, rp, cp, 2 if wino else 0
+        table = torch.frombuffer(bytearray(bytes((L.RcvPackJob * 1)(job))), dtype=torch.uint8).to(DEV)
+        out = torch.full((N, Ho, Wo, Cout), float("nan"), device=DEV)
+        pack = L.make_op(L.OP_PACK, 0, count=1, aux0=16 * rp * cp, p_in=table.data_ptr())
+        conv = L.make_op(L.OP_CONV, L.F_RESID, n=N, h=H, w=W, cin=Cin, cout=Cout, ho=Ho, wo=Wo, stride=s, dil=1, inmode=mode,
+                         aux0=2 if wino else 0, p_in=xd.data_ptr(), p_in_aux=xad.data_ptr(), p_in_c=cd.data_ptr(), p_w=wp.data_ptr(),
+                         p_out=out.data_ptr(), p_resid=rd.data_ptr())
+        lst = L.OpList([pack, conv])
+        label = lst.labels(h)[1]
+        assert label.startswith("conv_wino") == bool(wino), label
+        lst.run(h, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err <= (2e-6 if wino else 3e-6), (label, err)
+
+
+WGRAD_SHAPES = [(4, 15, 20, 64, 64, 1), (4, 30, 40, 32, 64, 2), (4, 15, 20, 64, 128, 1), (4, 15, 20, 128, 128, 1), (4, 30, 40, 32, 32, 1),
+                (4, 60, 80, 16, 16, 1), (4, 120, 160, 8, 16, 2), (2, 15, 20, 64, 64, 1), (4, 16, 20, 64, 64, 1), (4, 15, 24, 64, 64, 1),
+                (3, 5, 7, 64, 64, 1), (4, 10, 14, 128, 64, 1), (64, 15, 20, 64, 64, 1), (1, 30, 40, 64, 64, 1), (4, 7, 10, 128, 128, 1),
+                (2, 37, 53, 16, 32, 1), (2, 48, 64, 8, 8, 1), (3, 33, 47, 32, 16, 1)]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,s", WGRAD_SHAPES)
+@pytest.mark.parametrize("modes", [False, True])
+def test_filter_gradient_kernels_vs_fp64(N, H, W, Cin, Cout, s, modes):
+    from robocupvision_amd import _lib as L
+    h = L.handle(0)
+    gen = torch.Generator().manual_seed(2000 + H * W + Cout)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    G, P = _rand(gen, N, H, W, Cin), _rand(gen, N, Ho, Wo, Cout)
+    gc, pc, Pa = torch.rand(5, Cin, generator=gen) + 0.5, _rand(gen, 5, Cout, scale=0.5), _rand(gen, N, Ho, Wo, Cout)
+    Gd, Pd, gcd, pcd, Pad = (v.to(DEV) for v in (G, P, gc, pc, Pa))
+    dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=DEV)
+    db = torch.full((Cout,), float("nan"), device=DEV)
+    if modes:      # gathered operand: BatchNorm apply of the producer; pointwise operand: BatchNorm + ReLU backward of (g, r)
+        op = L.make_op(L.OP_WGRAD, L.F_BIAS, n=N, h=H, w=W, cin=Cin, ho=Ho, wo=Wo, cout=Cout, stride=s, dil=1, inmode=L.LOAD_AFFINE,
+                       inmode2=L.LOAD_GRAD_ENC, p_in=Gd.data_ptr(), p_in_c=gcd.data_ptr(), p_in2=Pd.data_ptr(), p_in2_aux=Pad.data_ptr(),
+                       p_in2_c=pcd.data_ptr())
+        x64, gy64 = _load_fp64(L.LOAD_AFFINE, G, G, gc, L), _load_fp64(L.LOAD_GRAD_ENC, P, Pa, pc, L)
+    else:
+        op = L.make_op(L.OP_WGRAD, L.F_BIAS, n=N, h=H, w=W, cin=Cin, ho=Ho, wo=Wo, cout=Cout, stride=s, dil=1, inmode=L.LOAD_PLAIN,
+                       inmode2=L.LOAD_PLAIN, p_in=Gd.data_ptr(), p_in2=Pd.data_ptr())
+        x64, gy64 = G.double(), P.double()
+    nb = L.op_workspace(h, op)
+    part = torch.zeros(max(nb // 4, 4), device=DEV)
+    op.p[L.RCV_P_PART] = part.data_ptr()
+    red = L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cin, cout=Cout, nsplit=op.i[L.RCV_I_NSPLIT], p_part=part.data_ptr(), p_out=dw.data_ptr(),
+                    p_bias=db.data_ptr())
+    lst = L.OpList([op, red])
+    lst.run(h, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(x64.permute(0, 3, 1, 2), (Cout, Cin, 3, 3), gy64.permute(0, 3, 1, 2), stride=s, padding=1)
+    refb = gy64.sum((0, 1, 2))
+    e = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
+    eb = float((db.double().cpu() - refb).abs().max() / refb.abs().max())
+    assert e <= 5e-7 and eb <= 5e-7, (lst.labels(h)[0], e, eb)
