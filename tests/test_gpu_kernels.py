@@ -110,3 +110,41 @@ def test_filter_gradient_kernels_vs_fp64(N, H, W, Cin, Cout, s, modes):
     e = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
     eb = float((db.double().cpu() - refb).abs().max() / refb.abs().max())
     assert e <= 5e-7 and eb <= 5e-7, (lst.labels(h)[0], e, eb)
+
+
+TCONV_SHAPES = [(2, 15, 20, 128, 64), (2, 30, 40, 64, 32), (2, 60, 80, 32, 16), (2, 120, 160, 16, 8), (3, 7, 9, 128, 64), (1, 33, 21, 64, 32),
+                (2, 24, 32, 32, 16), (4, 8, 10, 64, 64), (2, 20, 28, 16, 16), (1, 5, 6, 128, 128)]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", TCONV_SHAPES)
+@pytest.mark.parametrize("mode_name", ["affine", "grad_enc"])
+def test_transposed_conv_kernels_vs_fp64(N, H, W, Cin, Cout, mode_name):
+    """ConvTranspose2d(k3, s2, p1, output_padding 1) in its three kernel forms (all-parity LDS-DMA tile, merged-parity narrow tile,
+    phase-split fallback) -- the forward of the decoder blocks and the data gradient of the stride-2 convs: 3e-6 of the fp64 result."""
+    from robocupvision_amd import _lib as L
+    from robocupvision_amd.engine import MERGED_TCONV_MAX_COUT
+    h = L.handle(0)
+    mode = {"grad_enc": L.LOAD_GRAD_ENC, "affine": L.LOAD_AFFINE}[mode_name]
+    gen = torch.Generator().manual_seed(3000 + H * W + Cin)
+    x, xa, c = _rand(gen, N, H, W, Cin), _rand(gen, N, H, W, Cin), _rand(gen, 5, Cin, scale=0.5)
+    w, bias = _rand(gen, Cin, Cout, 3, 3, scale=0.1), _rand(gen, Cout)
+    ref = F.conv_transpose2d(_load_fp64(mode, x, xa, c, L).permute(0, 3, 1, 2), w.double(), bias.double(), stride=2, padding=1,
+                             output_padding=1).permute(0, 2, 3, 1)
+    xd, xad, cd, wd, bd = (v.to(DEV) for v in (x, xa, c, w, bias))
+    merged = 1 if Cout <= MERGED_TCONV_MAX_COUT else 0
+    rp, cp = (Cin + 3) // 4 * 4, (Cout * (4 if merged else 1) + 15) // 16 * 16
+    wp = torch.zeros((4 if merged else 9) * rp * cp, device=DEV)
+    job = L.RcvPackJob()
+    job.src, job.dst, job.D0, job.D1 = wd.data_ptr(), wp.data_ptr(), Cin, Cout
+    job.rows_from_d1, job.flip, job.rows_pad, job.cols_pad, job.merged = 0, 0, rp, cp, merged
+    table = torch.frombuffer(bytearray(bytes((L.RcvPackJob * 1)(job))), dtype=torch.uint8).to(DEV)
+    out = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device=DEV)
+    pack = L.make_op(L.OP_PACK, 0, count=1, aux0=9 * rp * cp, p_in=table.data_ptr())
+    tconv = L.make_op(L.OP_TCONV, L.F_BIAS, n=N, h=H, w=W, cin=Cin, cout=Cout, ho=2 * H, wo=2 * W, stride=2, dil=1, inmode=mode, aux0=merged,
+                      p_in=xd.data_ptr(), p_in_aux=xad.data_ptr(), p_in_c=cd.data_ptr(), p_w=wp.data_ptr(), p_bias=bd.data_ptr(),
+                      p_out=out.data_ptr())
+    lst = L.OpList([pack, tconv])
+    lst.run(h, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 3e-6, (lst.labels(h)[1], err)
