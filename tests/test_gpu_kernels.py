@@ -26,6 +26,8 @@ def _load_fp64(mode, x, aux, c, L):
     X, A, C = x.double(), aux.double(), c.double()
     if mode == L.LOAD_GRAD_ENC:        # rcv.h: v = aux > 0 ? c0*x + c1 + c2*aux : 0
         return torch.where(A > 0, C[0] * X + C[1] + C[2] * A, torch.zeros((), dtype=torch.float64))
+    if mode == L.LOAD_GRAD_DEC:        # v = c0*(aux*c3 + c4 > 0 ? x : 0) + c1 + c2*aux
+        return C[0] * torch.where(A * C[3] + C[4] > 0, X, torch.zeros((), dtype=torch.float64)) + C[1] + C[2] * A
     if mode == L.LOAD_AFFINE:          # v = x*c0 + c1
         return X * C[0] + C[1]
     return X
@@ -73,11 +75,12 @@ def test_conv_kernels_vs_fp64(N, H, W, Cin, Cout, s, mode_name):
 WGRAD_SHAPES = [(4, 15, 20, 64, 64, 1), (4, 30, 40, 32, 64, 2), (4, 15, 20, 64, 128, 1), (4, 15, 20, 128, 128, 1), (4, 30, 40, 32, 32, 1),
                 (4, 60, 80, 16, 16, 1), (4, 120, 160, 8, 16, 2), (2, 15, 20, 64, 64, 1), (4, 16, 20, 64, 64, 1), (4, 15, 24, 64, 64, 1),
                 (3, 5, 7, 64, 64, 1), (4, 10, 14, 128, 64, 1), (64, 15, 20, 64, 64, 1), (1, 30, 40, 64, 64, 1), (4, 7, 10, 128, 128, 1),
-                (2, 37, 53, 16, 32, 1), (2, 48, 64, 8, 8, 1), (3, 33, 47, 32, 16, 1)]
+                (2, 37, 53, 16, 32, 1), (2, 48, 64, 8, 8, 1), (3, 33, 47, 32, 16, 1), (2, 60, 80, 32, 64, 2), (2, 120, 160, 16, 32, 2),
+                (3, 14, 18, 64, 128, 2), (1, 96, 128, 8, 16, 2)]
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,s", WGRAD_SHAPES)
-@pytest.mark.parametrize("modes", [False, True])
+@pytest.mark.parametrize("modes", [False, True, "dec"])
 def test_filter_gradient_kernels_vs_fp64(N, H, W, Cin, Cout, s, modes):
     from robocupvision_amd import _lib as L
     h = L.handle(0)
@@ -88,7 +91,19 @@ def test_filter_gradient_kernels_vs_fp64(N, H, W, Cin, Cout, s, modes):
     Gd, Pd, gcd, pcd, Pad = (v.to(DEV) for v in (G, P, gc, pc, Pa))
     dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=DEV)
     db = torch.full((Cout,), float("nan"), device=DEV)
-    if modes:      # gathered operand: BatchNorm apply of the producer; pointwise operand: BatchNorm + ReLU backward of (g, r)
+    if modes == "dec":    # transposed-conv layer: gathered operand = the two-tensor gradient at the 2x plane, pointwise = the layer input
+        if s != 2:
+            pytest.skip("the transposed-conv form is the stride-2 one")
+        Ga = _rand(gen, N, H, W, Cin)
+        gc = _rand(gen, 5, Cin, scale=0.5)
+        Gad, gcd = Ga.to(DEV), gc.to(DEV)
+        pc = torch.rand(5, Cout, generator=gen) + 0.5
+        pcd = pc.to(DEV)
+        op = L.make_op(L.OP_WGRAD, 0, n=N, h=H, w=W, cin=Cin, ho=Ho, wo=Wo, cout=Cout, stride=2, dil=1, inmode=L.LOAD_GRAD_DEC,
+                       inmode2=L.LOAD_AFFINE, p_in=Gd.data_ptr(), p_in_aux=Gad.data_ptr(), p_in_c=gcd.data_ptr(), p_in2=Pd.data_ptr(),
+                       p_in2_c=pcd.data_ptr())
+        x64, gy64 = _load_fp64(L.LOAD_GRAD_DEC, G, Ga, gc, L), _load_fp64(L.LOAD_AFFINE, P, P, pc, L)
+    elif modes:      # gathered operand: BatchNorm apply of the producer; pointwise operand: BatchNorm + ReLU backward of (g, r)
         op = L.make_op(L.OP_WGRAD, L.F_BIAS, n=N, h=H, w=W, cin=Cin, ho=Ho, wo=Wo, cout=Cout, stride=s, dil=1, inmode=L.LOAD_AFFINE,
                        inmode2=L.LOAD_GRAD_ENC, p_in=Gd.data_ptr(), p_in_c=gcd.data_ptr(), p_in2=Pd.data_ptr(), p_in2_aux=Pad.data_ptr(),
                        p_in2_c=pcd.data_ptr())
@@ -100,15 +115,16 @@ def test_filter_gradient_kernels_vs_fp64(N, H, W, Cin, Cout, s, modes):
     nb = L.op_workspace(h, op)
     part = torch.zeros(max(nb // 4, 4), device=DEV)
     op.p[L.RCV_P_PART] = part.data_ptr()
+    has_bias = bool(op.flags & L.F_BIAS)
     red = L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cin, cout=Cout, nsplit=op.i[L.RCV_I_NSPLIT], p_part=part.data_ptr(), p_out=dw.data_ptr(),
-                    p_bias=db.data_ptr())
+                    p_bias=db.data_ptr() if has_bias else 0)
     lst = L.OpList([op, red])
     lst.run(h, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     ref = torch.nn.grad.conv2d_weight(x64.permute(0, 3, 1, 2), (Cout, Cin, 3, 3), gy64.permute(0, 3, 1, 2), stride=s, padding=1)
     refb = gy64.sum((0, 1, 2))
     e = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
-    eb = float((db.double().cpu() - refb).abs().max() / refb.abs().max())
+    eb = float((db.double().cpu() - refb).abs().max() / refb.abs().max()) if has_bias else 0.0
     assert e <= 5e-7 and eb <= 5e-7, (lst.labels(h)[0], e, eb)
 
 
