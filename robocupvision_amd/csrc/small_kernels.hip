@@ -227,18 +227,20 @@ __global__ void concat_kernel(const float* __restrict__ t, const float* __restri
 template <int CIN, bool FUSED>
 struct ClsRaw { float4 a[CIN / 4]; float4 b[FUSED ? CIN / 4 : 1]; };
 
+// rch: channels per pixel of the skip tensor r (CIN for the decoder's skip add; fewer for LabelProp's `x[:, 0:8] += top`, model.py:565:
+// the skip then reaches only the first rch input channels)
 template <int CIN, bool FUSED>
-__device__ __forceinline__ void cls_load_raw(ClsRaw<CIN, FUSED>& o, const float* __restrict__ x, const float* __restrict__ r, size_t p) {
+__device__ __forceinline__ void cls_load_raw(ClsRaw<CIN, FUSED>& o, const float* __restrict__ x, const float* __restrict__ r, size_t p, int rch = CIN) {
 #pragma unroll
   for (int q = 0; q < CIN / 4; ++q) {
     o.a[q] = sld4(x + p * CIN + 4 * q);
-    if (FUSED) o.b[FUSED ? q : 0] = sld4(r + p * CIN + 4 * q);
+    if (FUSED) o.b[FUSED ? q : 0] = 4 * q < rch ? sld4(r + p * rch + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
 template <int CIN, bool FUSED>
 __device__ __forceinline__ void cls_form_up(float (&v)[CIN], const ClsRaw<CIN, FUSED>& raw, const float* __restrict__ tc,
-                                            const float* __restrict__ rc, int mode2) {
+                                            const float* __restrict__ rc, int mode2, int rch = CIN) {
 #pragma unroll
   for (int q = 0; q < CIN / 4; ++q) {
     float4 a = raw.a[q];
@@ -247,8 +249,9 @@ __device__ __forceinline__ void cls_form_up(float (&v)[CIN], const ClsRaw<CIN, F
       a.x = fmaxf(fmaf(a.x, s.x, h.x), 0.f); a.y = fmaxf(fmaf(a.y, s.y, h.y), 0.f);
       a.z = fmaxf(fmaf(a.z, s.z, h.z), 0.f); a.w = fmaxf(fmaf(a.w, s.w, h.w), 0.f);
       float4 b = raw.b[FUSED ? q : 0];
-      if (mode2 != RCV_LOAD_PLAIN) {
-        const float4 s2 = sld4(rc + 4 * q), h2 = sld4(rc + CIN + 4 * q);
+      if (4 * q >= rch) b = make_float4(0.f, 0.f, 0.f, 0.f);                 // input channels the skip does not reach
+      else if (mode2 != RCV_LOAD_PLAIN) {
+        const float4 s2 = sld4(rc + 4 * q), h2 = sld4(rc + rch + 4 * q);
         b.x = fmaf(b.x, s2.x, h2.x); b.y = fmaf(b.y, s2.y, h2.y); b.z = fmaf(b.z, s2.z, h2.z); b.w = fmaf(b.w, s2.w, h2.w);
         if (mode2 == RCV_LOAD_AFFINE_RELU) { b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f); }
       }
@@ -260,10 +263,10 @@ __device__ __forceinline__ void cls_form_up(float (&v)[CIN], const ClsRaw<CIN, F
 
 template <int CIN, bool FUSED>
 __device__ __forceinline__ void cls_load_up(float (&v)[CIN], const float* __restrict__ x, const float* __restrict__ tc,
-                                            const float* __restrict__ r, const float* __restrict__ rc, int mode2, size_t p) {
+                                            const float* __restrict__ r, const float* __restrict__ rc, int mode2, size_t p, int rch = CIN) {
   ClsRaw<CIN, FUSED> raw;
-  cls_load_raw<CIN, FUSED>(raw, x, r, p);
-  cls_form_up<CIN, FUSED>(v, raw, tc, rc, mode2);
+  cls_load_raw<CIN, FUSED>(raw, x, r, p, rch);
+  cls_form_up<CIN, FUSED>(v, raw, tc, rc, mode2, rch);
 }
 
 // CE: the weighted cross-entropy partial sums, the arg-max mask and the pixel-accuracy count of RCV_OP_CE_FWD are taken from the
@@ -273,7 +276,7 @@ __global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restr
                                float* __restrict__ out, int N, int HW, int COUT, const float* __restrict__ tc,
                                const float* __restrict__ r, const float* __restrict__ rc, int mode2,
                                const int64_t* __restrict__ target, const float* __restrict__ cw, float* __restrict__ part,
-                               uint8_t* __restrict__ argmax) {
+                               uint8_t* __restrict__ argmax, int rch) {
   __shared__ float ws[CLS_MAX_OUT * CIN + CLS_MAX_OUT];
   __shared__ double sh[3][4];
   for (int e = threadIdx.x; e < COUT * CIN; e += blockDim.x) ws[e] = w[e];
@@ -284,7 +287,7 @@ __global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restr
   // (no software prefetch here: measured 0.205 vs 0.194 ms -- this kernel already streams at 4.7 TB/s; the backward one gained 30 %)
   for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
     float v[CIN];
-    cls_load_up<CIN, FUSED>(v, x, tc, r, rc, mode2, p);
+    cls_load_up<CIN, FUSED>(v, x, tc, r, rc, mode2, p, rch);
     const size_t n = p / HW, hw = p % HW;
     float lg[CLS_MAX_OUT];
 #pragma unroll
@@ -1116,22 +1119,27 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       const int mode2 = op->i[RCV_I_AUX0];
       const int64_t* tgt = (const int64_t*)op->p[RCV_P_IN2]; const float* cw = (const float*)op->p[RCV_P_X0];
       float* part = (float*)op->p[RCV_P_PART]; uint8_t* am = (uint8_t*)op->p[RCV_P_X2];
+      // i[RCV_I_AUX1]: channels of the skip tensor when it is narrower than the classifier input (0 = Cin)
+      const int rch = (fused && op->i[RCV_I_AUX1] > 0) ? op->i[RCV_I_AUX1] : Cin;
       if (fused) {
-        RCV_CHECK_ARG(Cin == 8 && tc && r && (mode2 == RCV_LOAD_PLAIN || rc), "classifier (fused decoder output): operands missing");
+        RCV_CHECK_ARG(tc && r && (mode2 == RCV_LOAD_PLAIN || rc), "classifier (fused decoder output): operands missing");
+        RCV_CHECK_ARG(rch % 4 == 0 && rch >= 4 && rch <= Cin && (Cin == 8 || !with_ce), "classifier (fused decoder output): %d skip channels for %d inputs", rch, Cin);
         RCV_CHECK_ARG(mode2 == RCV_LOAD_PLAIN || mode2 == RCV_LOAD_AFFINE || mode2 == RCV_LOAD_AFFINE_RELU, "classifier: skip load mode %d", mode2);
       }
       if (with_ce) {
         RCV_CHECK_ARG(fused && Cout <= CE_MAX_C && tgt && part && op->p[RCV_P_X1], "classifier + cross entropy: needs the fused decoder input, target, workspace, loss_out");
         RCV_CHECK_ARG(op->i[RCV_I_NPART] == gce, "classifier + cross entropy: workspace rows %d != %d", op->i[RCV_I_NPART], gce);
-        hipLaunchKernelGGL((cls_fwd_kernel<8, true, true>), dim3(gce), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am);
+        hipLaunchKernelGGL((cls_fwd_kernel<8, true, true>), dim3(gce), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am, rch);
         RCV_HIP(hipGetLastError());
         hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)part, gce, (float*)op->p[RCV_P_X1]);
+      } else if (fused && Cin == 16) {
+        hipLaunchKernelGGL((cls_fwd_kernel<16, true, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am, rch);
       } else if (fused) {
-        hipLaunchKernelGGL((cls_fwd_kernel<8, true, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am);
+        hipLaunchKernelGGL((cls_fwd_kernel<8, true, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am, rch);
       } else if (Cin == 8)
-        hipLaunchKernelGGL((cls_fwd_kernel<8, false, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am);
+        hipLaunchKernelGGL((cls_fwd_kernel<8, false, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am, rch);
       else
-        hipLaunchKernelGGL((cls_fwd_kernel<16, false, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am);
+        hipLaunchKernelGGL((cls_fwd_kernel<16, false, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am, rch);
       break;
     }
     case RCV_OP_CLS_BWD: {

@@ -442,6 +442,7 @@ class Engine:
                 if tuple(w.shape[2:]) == (1, 1) and src.kind == "fused_up":
                     tt, skip = src.fused
                     fwd.append(L.make_op(L.OP_CLS_FWD, L.F_FUSED_UP, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, aux0=skip.load_mode,
+                                         aux1=getattr(src, "fused_rch", 0),
                                          p_in=tt.data_ptr(), p_in_c=src.consts.data_ptr(), p_x3=skip.buf.data_ptr(), p_x4=_ptr(skip.consts),
                                          p_w=w.data_ptr(), p_bias=_ptr(b), p_out=logits.data_ptr()))
                 elif tuple(w.shape[2:]) == (1, 1):
@@ -469,6 +470,15 @@ class Engine:
                 src, add = ref(d["src"]), ref(d["add"])
                 if (add.H, add.W) != (src.H, src.W) or add.C > src.C:
                     raise L.RcvError("add_slice: operand shapes do not match")
+                if (FUSE_UP_INTO_CLS and not training and src.kind == "affine_relu" and src.C == 16 and add.C % 4 == 0 and add.buf is not None
+                        and add.input_index is None and src.input_index is None and add.kind in ("plain", "affine", "affine_relu")
+                        and only_consumer_is_cls1x1(node.idx)):
+                    # LabelProp's tail (model.py:563-567): the 1x1 classifier forms relu(bn(t)) and adds the skip to its first add.C input
+                    # channels itself (RCV_F_FUSED_UP with i[RCV_I_AUX1] = add.C): no RCV_OP_MATERIALIZE / RCV_OP_ADD_SLICE passes
+                    node.out = Value("fused_up", None, src.C, src.H, src.W, src.consts, node)
+                    node.out.fused = (src.buf, add)
+                    node.out.fused_rch = add.C
+                    continue
                 out = self._alloc(plan, N, src.H, src.W, src.C)
                 op = L.make_op(L.OP_MATERIALIZE, 0, n=N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
                                p_in_c=_ptr(src.consts), p_out=out.data_ptr())
@@ -869,7 +879,8 @@ class Engine:
             nbytes = 4.0 * i[L.RCV_I_NPART] * 2 * cout
         elif k == L.OP_CLS_FWD:
             flops = 2.0 * cin * cout * px
-            nbytes = 4.0 * px * (cin * (2 if op.flags & L.F_FUSED_UP else 1) + cout) + (px * 9.0 if op.flags & L.F_FUSED_CE else 0.0)
+            skip_c = (i[L.RCV_I_AUX1] or cin) if op.flags & L.F_FUSED_UP else 0
+            nbytes = 4.0 * px * (cin + skip_c + cout) + (px * 9.0 if op.flags & L.F_FUSED_CE else 0.0)
         elif k == L.OP_CLS_BWD:
             flops = 2.0 * 2 * cin * cout * px        # data gradient + filter gradient
             src = cin * (2 if op.flags & L.F_FUSED_UP else 1)
