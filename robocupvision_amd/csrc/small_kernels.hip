@@ -873,15 +873,19 @@ __global__ void adam_l1_kernel(float* __restrict__ p, const float* __restrict__ 
     double a = (double)asum, dummy = 0.0;
     block_sum2_d(a, dummy);
     if (threadIdx.x == 0) {
-      part[blockIdx.x] = a;
-      __threadfence();                                   // the row is visible device-wide before the ticket is taken
+      // The row and the ticket are both device-scope atomics, i.e. performed at the memory side of the (per-XCD, mutually
+      // non-coherent) L2s, and the exchange has returned before the ticket is requested: the row is in place when its ticket is
+      // counted.  (A __threadfence() here is a write-back of the XCD's whole L2 -- holding the 13 MB this launch just wrote -- per
+      // workgroup: it cost most of the kernel's time.)
+      (void)atomicExch(reinterpret_cast<unsigned long long*>(part + blockIdx.x), (unsigned long long)__double_as_longlong(a));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
     if (is_last) {
-      __threadfence();
       double s = 0.0;
-      for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) s += __builtin_nontemporal_load(part + i);
+      for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x)      // device-scope loads: never served from this XCD's L2
+        s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(part + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       dummy = 0.0;
       __syncthreads();                                   // block_sum2_d's scratch is reused
       block_sum2_d(s, dummy);
