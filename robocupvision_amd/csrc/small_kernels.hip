@@ -333,6 +333,56 @@ __global__ void cls_fwd_kernel(const float* __restrict__ x, const float* __restr
   }
 }
 
+// 16-channel classifier (LabelProp, model.py:567): FOUR lanes per pixel, one 16-byte channel quad each, so that every load instruction
+// of a wave reads 1 KB of consecutive memory (with a lane per pixel each of its four loads touched 64 different lines: 1.5 TB/s).  The
+// partial dot products meet through two butterfly steps; lane q of a pixel then stores classes q and q + 4.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void cls_fwd16_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int N, int HW, int COUT, const float* __restrict__ tc,
+                                                        const float* __restrict__ r, const float* __restrict__ rc, int mode2, int rch) {
+  constexpr int CIN = 16;
+  __shared__ float ws[CLS_MAX_OUT * CIN + CLS_MAX_OUT];
+  for (int e = threadIdx.x; e < CLS_MAX_OUT * CIN; e += blockDim.x) ws[e] = e < COUT * CIN ? w[e] : 0.f;
+  for (int e = threadIdx.x; e < CLS_MAX_OUT; e += blockDim.x) ws[CLS_MAX_OUT * CIN + e] = (bias && e < COUT) ? bias[e] : 0.f;
+  __syncthreads();
+  const int q = threadIdx.x & 3;
+  float4 s = make_float4(1.f, 1.f, 1.f, 1.f), h = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s, h2 = h;
+  if (FUSED) {
+    s = sld4(tc + 4 * q); h = sld4(tc + CIN + 4 * q);
+    if (4 * q < rch && mode2 != RCV_LOAD_PLAIN) { s2 = sld4(rc + 4 * q); h2 = sld4(rc + rch + 4 * q); }
+  }
+  const bool has_skip = FUSED && 4 * q < rch;
+  const size_t total = (size_t)N * HW;
+  for (size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; p < total; p += ((size_t)gridDim.x * blockDim.x) >> 2) {
+    float4 a = sld4(x + p * CIN + 4 * q);
+    if (FUSED) {
+      a.x = fmaxf(fmaf(a.x, s.x, h.x), 0.f); a.y = fmaxf(fmaf(a.y, s.y, h.y), 0.f);
+      a.z = fmaxf(fmaf(a.z, s.z, h.z), 0.f); a.w = fmaxf(fmaf(a.w, s.w, h.w), 0.f);
+      if (has_skip) {
+        float4 b = sld4(r + p * rch + 4 * q);
+        if (mode2 != RCV_LOAD_PLAIN) {
+          b.x = fmaf(b.x, s2.x, h2.x); b.y = fmaf(b.y, s2.y, h2.y); b.z = fmaf(b.z, s2.z, h2.z); b.w = fmaf(b.w, s2.w, h2.w);
+          if (mode2 == RCV_LOAD_AFFINE_RELU) { b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f); }
+        }
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+    }
+    float lg[CLS_MAX_OUT];
+#pragma unroll
+    for (int c = 0; c < CLS_MAX_OUT; ++c) {
+      const float* wc = ws + c * CIN + 4 * q;
+      float u = fmaf(a.x, wc[0], fmaf(a.y, wc[1], fmaf(a.z, wc[2], a.w * wc[3])));
+      u += __shfl_xor(u, 1);
+      u += __shfl_xor(u, 2);
+      lg[c] = u + ws[CLS_MAX_OUT * CIN + c];
+    }
+    const size_t n = p / HW, hw = p % HW;
+#pragma unroll
+    for (int c = 0; c < CLS_MAX_OUT; ++c)
+      if ((c & 3) == q && c < COUT) out[(n * COUT + c) * HW + hw] = lg[c];
+  }
+}
+
 // classifier backward: d_up[p][k] = sum_c dl[c][p] W[c][k];  dW[c][k] = sum_p dl[c][p] up[p][k];
 // db[c] = sum_p dl[c][p];  optional decoder BN-backward statistics of d_up against t.
 // CE: d loss / d logits is recomputed from (t, r, W, b, target) instead of being read: RCV_OP_CE_BWD and its tensor disappear (the
@@ -1136,14 +1186,14 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
         hipLaunchKernelGGL((cls_fwd_kernel<8, true, true>), dim3(gce), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am, rch);
         RCV_HIP(hipGetLastError());
         hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, s, (const float*)part, gce, (float*)op->p[RCV_P_X1]);
-      } else if (fused && Cin == 16) {
-        hipLaunchKernelGGL((cls_fwd_kernel<16, true, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am, rch);
+      } else if (Cin == 16) {
+        const int g16 = stream_grid(h, (size_t)N * H * W * 4, 256);        // four lanes per pixel
+        if (fused) hipLaunchKernelGGL((cls_fwd16_kernel<true>), dim3(g16), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, rch);
+        else hipLaunchKernelGGL((cls_fwd16_kernel<false>), dim3(g16), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, rch);
       } else if (fused) {
         hipLaunchKernelGGL((cls_fwd_kernel<8, true, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am, rch);
-      } else if (Cin == 8)
+      } else
         hipLaunchKernelGGL((cls_fwd_kernel<8, false, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am, rch);
-      else
-        hipLaunchKernelGGL((cls_fwd_kernel<16, false, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am, rch);
       break;
     }
     case RCV_OP_CLS_BWD: {
