@@ -353,6 +353,50 @@ def test_trainer_fused_step_vs_golden(golden, tag):
     assert tr.pop_metrics()["loss"] < m["loss"]
 
 
+def test_training_trajectory_vs_oracle():
+    """Eight consecutive steps (a fresh batch each) of Trainer -- fused loss, fused Adam + L1, plan reuse, running statistics -- beside
+    eight steps of the CPU oracle (train.py:43-74 with stock Adam) from the same initial state.  The loss of every step agrees within
+    2e-3.  Parameter trajectories under Adam are chaotic at fp32 resolution (an entry whose gradient is rounding noise still moves by
+    +-lr): the yardstick is the oracle against ITSELF with the inputs scaled by (1 + 1e-6) -- after eight steps those two runs sit
+    0.2-0.3 of the distance travelled apart (rms, measured) -- and the HIP run must be no further from the oracle than twice that
+    (all parameters pooled; per tensor a loose 0.6 of the distance travelled); the running BatchNorm statistics likewise (+ 2e-3 of their scale)."""
+    from robocupvision_amd.train import Trainer
+    ctor = dict(noScale=False, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128)
+    model = build(ctor)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    st = O.TrainState(model.state_dict(), O.NetConfig(**ctor), ce_weight=CE_W, lr=1e-3, decay=1e-6)
+    st_p = O.TrainState(model.state_dict(), O.NetConfig(**ctor), ce_weight=CE_W, lr=1e-3, decay=1e-6)      # the perturbed twin
+    model = model.to(DEV)
+    tr = Trainer(model, class_weights=CE_W, lr=1e-3, decay=1e-6)
+    for it in range(8):
+        x, t = O.synthetic_batch(2, 48, 64, seed=100 + it)
+        ref = O.train_step(st, x, t)
+        O.train_step(st_p, x * (1 + 1e-6), t)
+        tr.step(x.to(DEV), t.to(DEV))
+        met = tr.pop_metrics()
+        assert abs(met["loss"] - (ref["ce"] + ref["reg"])) <= 2e-3 * abs(ref["ce"] + ref["reg"]), (it, met["loss"], ref["ce"] + ref["reg"])
+    sd = model.state_dict()
+    rms = lambda u: float(u.pow(2).mean().sqrt())
+    pooled = {"hip": 0.0, "twin": 0.0, "trav": 0.0}
+    stats = {"hip": 0.0, "twin": 0.0, "n": 0}
+    for k, v in st.sd.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v) == 8
+            continue
+        a, b, c, b0 = sd[k].detach().double().cpu(), v.detach().double(), st_p.sd[k].detach().double(), sd0[k].double()
+        if "running" in k:          # they follow the activations, i.e. the diverging weights: the same yardstick + 2e-3 of their scale
+            scale = float(b.abs().max()) + 1e-12
+            assert float((a - b).abs().max()) <= 5.0 * float((c - b).abs().max()) + 1e-2 * scale + 2e-5, (k, float((a - b).abs().max()), scale)
+            stats["hip"] += float(((a - b) / scale).pow(2).sum()); stats["twin"] += float(((c - b) / scale).pow(2).sum()); stats["n"] += a.numel()
+            continue
+        assert float((a - b).abs().max()) <= 16 * 1e-3 * 1.05, (k, float((a - b).abs().max()))        # both moved at most 8 * lr
+        assert rms(a - b) <= 0.6 * rms(b - b0) + 1e-7, (k, rms(a - b), rms(b - b0))                     # per tensor: a loose sanity bound
+        pooled["hip"] += float((a - b).pow(2).sum()); pooled["twin"] += float((c - b).pow(2).sum()); pooled["trav"] += float((b - b0).pow(2).sum())
+    # all parameters pooled (small tensors fluctuate): no further from the oracle than twice the oracle's distance from its perturbed twin
+    assert pooled["hip"] ** 0.5 <= 2.0 * pooled["twin"] ** 0.5 + 0.02 * pooled["trav"] ** 0.5, pooled
+    assert (stats["hip"] / stats["n"]) ** 0.5 <= 2.5 * (stats["twin"] / stats["n"]) ** 0.5 + 2e-3, stats      # running statistics, scale-relative rms
+
+
 def test_trainer_metrics_in_optimizer_launch(golden):
     """The Adam launch books loss / reg / #correct / steps itself (one workgroup ticket per launch); over several steps it
     must agree with the bookkeeping done with separate reductions (decay*sum|p| BEFORE each update, the loss row, a count)."""
