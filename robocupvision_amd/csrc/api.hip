@@ -212,13 +212,22 @@ int rcv_run_timed(rcv_handle* h, const rcv_op* ops, int n, void* stream, float* 
   }
   int rc = RCV_OK;
   (void)hipEventRecord(ev[0], s);
+  int last = 0;                      // index of the event that closes the latest op that launched something
+  int* opens = new int[n];           // event that opens op k (RCV_OP_NOP slots launch nothing and take no event: rcv_run skips them too)
   for (int k = 0; k < n && rc == RCV_OK; ++k) {
+    opens[k] = last;
+    if (ops[k].kind == RCV_OP_NOP) continue;
     rc = dispatch(h, &ops[k], s, nullptr);
     (void)hipEventRecord(ev[k + 1], s);
+    last = k + 1;
   }
   if (hipStreamSynchronize(s) != hipSuccess && rc == RCV_OK) { rcv_set_error("rcv_run_timed: stream sync failed"); rc = RCV_E_HIP; }
   if (rc == RCV_OK)
-    for (int k = 0; k < n; ++k) (void)hipEventElapsedTime(&ms[k], ev[k], ev[k + 1]);
+    for (int k = 0; k < n; ++k) {
+      if (ops[k].kind == RCV_OP_NOP) ms[k] = 0.f;
+      else (void)hipEventElapsedTime(&ms[k], ev[opens[k]], ev[k + 1]);
+    }
+  delete[] opens;
   for (int k = 0; k <= n; ++k) (void)hipEventDestroy(ev[k]);
   delete[] ev;
   return rc;
