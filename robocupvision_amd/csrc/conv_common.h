@@ -28,6 +28,7 @@ struct ConvArgs {
   int xpitch;                  // floats per staged input pixel (see conv_xpitch)
   int xk;                      // conv_dma_kernel: channels per staged input chunk (8 or 16)
   FastDiv fdWt, fdIW;
+  FastDiv fdTX, fdTY;          // tiles_x, tiles_y (narrow kernel: tile decode on the scalar unit)
 #ifdef RCV_STAMPS
   unsigned long long* stamps;  // diagnostic build: per wave [12] cycle sums (conv_dma_kernel)
 #endif

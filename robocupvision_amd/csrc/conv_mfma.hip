@@ -1059,6 +1059,7 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   a.xk = pl.xk;
   a.xpitch = conv_xpitch((pl.dma || pl.wino) ? pl.xk : pl.CK, pl.kind == KIND_GATHER ? a.stride : 1);
   a.fdWt = make_fastdiv(pl.Wt); a.fdIW = make_fastdiv(pl.IW);
+  a.fdTX = make_fastdiv(pl.tiles_x); a.fdTY = make_fastdiv(pl.tiles_y);
 #ifdef RCV_STAMPS
   a.stamps = (unsigned long long*)op->p[RCV_P_X5];
 #endif

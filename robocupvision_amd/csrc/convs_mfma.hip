@@ -15,27 +15,65 @@
 // (WM blocks of 16) for its WN blocks of 16 pixels.  Kinds: KIND_GATHER (stride 1|2, dilation 1|2) and
 // KIND_TMERGED (transposed conv, merged-parity layout, see conv_mfma.hip).
 #include <stdlib.h>
+#include <type_traits>
 #include "conv_common.h"
+
+// 16-byte accesses at a 32-bit byte offset from a uniform base: the address is (scalar base + vector offset), no 64-bit vector
+// arithmetic per access (the host keeps every tensor this kernel touches below 4 GiB)
+__device__ __forceinline__ float4 ld4b(const float* base, uint32_t byte_off) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st4b(float* base, uint32_t byte_off, float4 v) {
+  *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+
+// Per-tile scalars of the persistent loop (all uniform: they live in SGPRs)
+struct NarrowTile {
+  int n, oy0, ox0;          // image, first staged input row / column (may be negative: padding)
+  uint32_t obase;           // byte offset of the tile's first output pixel (channel 0)
+  int rlim, wlim;           // output rows / columns of the tile that lie inside the plane
+  bool interior;            // the whole staged input tile lies inside the plane: no padding, no per-pixel bounds work
+};
+
+template <int KIND>
+__device__ __forceinline__ NarrowTile narrow_decode(const ConvArgs& a, int t) {
+  NarrowTile ti;
+  const int q1 = fd_div(t, a.fdTX), tx_i = t - q1 * a.tiles_x;
+  ti.n = fd_div(q1, a.fdTY);
+  const int ty_i = q1 - ti.n * a.tiles_y;
+  const int y0 = ty_i * a.R, x0 = tx_i * a.Wt;
+  if (KIND == KIND_GATHER) {
+    ti.oy0 = y0 * a.stride - a.dil; ti.ox0 = x0 * a.stride - a.dil;
+    ti.obase = (uint32_t)(((ti.n * a.Ho + y0) * a.Wo + x0) * a.Cout) * 4u;
+    ti.rlim = a.Ho - y0; ti.wlim = a.Wo - x0;
+  } else {
+    ti.oy0 = y0; ti.ox0 = x0;
+    ti.obase = (uint32_t)(((ti.n * a.Ho + 2 * y0) * a.Wo + 2 * x0) * a.Cout) * 4u;
+    ti.rlim = a.H - y0; ti.wlim = a.W - x0;
+  }
+  ti.interior = ti.oy0 >= 0 && ti.ox0 >= 0 && ti.oy0 + a.IH <= a.H && ti.ox0 + a.IW <= a.W;
+  return ti;
+}
 
 template <int MODE, int XMAX, int AMAX, int CK>
 __device__ __forceinline__ void narrow_write_x(const ConvArgs& a, float* xl, const float* cl, const float4 (&px)[XMAX],
-                                               const float4 (&pa)[AMAX], uint32_t okmask, int tid) {
+                                               const float4 (&pa)[AMAX], uint32_t okmask, bool interior, int tid) {
   constexpr int Q = CK / 4, STEP = 256 / Q;
   const int S = a.xpitch;
-  const int q = tid % Q;
+  const int q = tid % Q, lpix = tid / Q;
   const int npix = a.IH * a.IW;
   float4 k[5];
   if (MODE != RCV_LOAD_PLAIN && MODE != RCV_LOAD_NCHW) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) k[j] = *reinterpret_cast<const float4*>(cl + j * a.Cin + 4 * q);
   }
+  float* d0 = xl + lpix * S + 4 * q;
 #pragma unroll
   for (int u = 0; u < XMAX; ++u) {
-    const int pix = tid / Q + u * STEP;
-    if (pix < npix) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((okmask >> u) & 1u) v = xform4<MODE>(px[u], pa[AMAX == XMAX ? u : 0], k);   // zero padding AFTER the transform
-      float* d = xl + pix * S + 4 * q;
+    if (lpix < npix - u * STEP) {                // (right side uniform)
+      float4 v = xform4<MODE>(px[u], pa[AMAX == XMAX ? u : 0], k);
+      if (!interior && !((okmask >> u) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding AFTER the transform
+      float* d = d0 + u * STEP * S;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
   }
@@ -58,14 +96,29 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
   float* xl = smem + a.wl_floats;          // [IH*IW][S]
   float* cl = xl + a.xl_floats;            // [5][Cin]
   float* red = cl + 5 * a.CinP + 16;       // [WAVES][2][COT]
+  float* ec = red + WAVES * 2 * COT;       // [4][COT]: bias, epilogue scale, epilogue shift, batch mean per virtual output channel
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int npix = a.IH * a.IW;
+  const bool nchw = a.in_mode == RCV_LOAD_NCHW;
+  const bool need_e = a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC;
 
-  // ---- once per workgroup: load constants and the whole filter
-  if (a.in_c && a.in_mode != RCV_LOAD_PLAIN && a.in_mode != RCV_LOAD_NCHW)
+  // ---- once per workgroup: load constants, epilogue constants and the whole filter
+  if (a.in_c && a.in_mode != RCV_LOAD_PLAIN && !nchw)
     for (int e = tid; e < 5 * a.Cin; e += NT) cl[e] = a.in_c[e];
+  for (int e = tid; e < 4 * COT; e += NT) {
+    const int which = e / COT, cov = e - which * COT;
+    const int co = KIND == KIND_TMERGED ? cov % a.Cout : cov;
+    float v = 0.f;
+    if (cov < a.CoutV) {
+      if (which == 0 && (a.flags & RCV_F_BIAS)) v = a.bias[co];
+      if (which == 1 && a.stats == RCV_STATS_BWD_DEC) v = a.epi_c[co];
+      if (which == 2 && a.stats == RCV_STATS_BWD_DEC) v = a.epi_c[a.Cout + co];
+      if (which == 3 && need_e) v = a.epi_c[2 * a.Cout + co];
+    }
+    ec[e] = v;
+  }
   for (int e = tid; e < NTAPS * CK * C4; e += NT) {
     const int row = e / C4, c4 = e % C4;
     const int j = row / CK, ck = row % CK;
@@ -74,47 +127,66 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
     *reinterpret_cast<float4*>(wl + row * WS + 4 * c4) = v;
   }
 
+  // ---- lane constants of the staging slots (the same for every tile): position inside the staged tile, byte offset relative to the
+  // tile's first input pixel.  Slots past the tile sit at row 2^24: never inside the plane.
+  const int q = tid % Q, lpix = tid / Q;
+  int siy[XMAX], six[XMAX];
+  uint32_t rel4[XMAX];
+  uint32_t slotmask = 0;
+#pragma unroll
+  for (int u = 0; u < XMAX; ++u) {
+    const int pix = lpix + u * STEP;
+    const int pixc = pix < npix ? pix : npix - 1;
+    const int iy = fd_div(pixc, a.fdIW), ix = pixc - iy * a.IW;
+    siy[u] = pix < npix ? iy : (1 << 24);
+    six[u] = ix;
+    rel4[u] = (uint32_t)((iy * a.W + ix) * a.Cin + 4 * q) * 4u;
+    slotmask |= (pix < npix ? 1u : 0u) << u;
+  }
+
   // ---- prefetch registers
   float4 px[XMAX], pa[AMAX];
   uint32_t okmask = 0;
-  auto prefetch = [&](int t) {
-    const TileInfo ti = decode_tile<KIND>(a, t, COT);
-    okmask = 0;
-    if (a.in_mode == RCV_LOAD_NCHW) {
+  auto prefetch = [&](const NarrowTile& ti) {
+    if (nchw) {
+      okmask = 0;
 #pragma unroll
       for (int u = 0; u < XMAX; ++u) {
-        const int pix = tid + u * NT;
         px[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (Q == 1 && pix < npix) {
-          const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
-          const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
-          if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
-            okmask |= 1u << u;
-            const size_t plane = (size_t)a.H * a.W;
-            const size_t base = (size_t)ti.n * a.Cin * plane + (size_t)gy * a.W + gx;
-            if (0 < a.Cin) px[u].x = a.in[base];
-            if (1 < a.Cin) px[u].y = a.in[base + plane];
-            if (2 < a.Cin) px[u].z = a.in[base + 2 * plane];
-            if (3 < a.Cin) px[u].w = a.in[base + 3 * plane];
-          }
+        const int gy = ti.oy0 + siy[u], gx = ti.ox0 + six[u];
+        if (Q == 1 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
+          okmask |= 1u << u;
+          const size_t plane = (size_t)a.H * a.W;
+          const size_t base = (size_t)ti.n * a.Cin * plane + (size_t)gy * a.W + gx;
+          if (0 < a.Cin) px[u].x = a.in[base];
+          if (1 < a.Cin) px[u].y = a.in[base + plane];
+          if (2 < a.Cin) px[u].z = a.in[base + 2 * plane];
+          if (3 < a.Cin) px[u].w = a.in[base + 3 * plane];
         }
       }
     } else {
-      // Branch-free: clamped addresses, validity kept in okmask (write_x zeroes what lies outside).  With the loads inside divergent
-      // branches the compiler waits for each of them on the spot, and nothing stays in flight across the contraction.
-      const int q = tid % Q;
+      // Branch-free loads (behind divergent branches the compiler waits for each load on the spot and nothing stays in flight across
+      // the contraction): one address add per slot on interior tiles, bounds tests and a select on the tiles that touch the border.
+      // A slot outside the plane reads byte 0 of the tensor and is zeroed when it is written to LDS.
+      const uint32_t tb4 = (uint32_t)(((ti.n * a.H + ti.oy0) * a.W + ti.ox0) * a.Cin) * 4u;
+      uint32_t bo[XMAX];
+      if (ti.interior) {
+        okmask = slotmask;
+#pragma unroll
+        for (int u = 0; u < XMAX; ++u) bo[u] = tb4 + rel4[u];
+      } else {
+        okmask = 0;
+#pragma unroll
+        for (int u = 0; u < XMAX; ++u) {
+          const bool inside = (unsigned)(ti.oy0 + siy[u]) < (unsigned)a.H && (unsigned)(ti.ox0 + six[u]) < (unsigned)a.W;
+          okmask |= (inside ? 1u : 0u) << u;
+          bo[u] = inside ? tb4 + rel4[u] : 0u;
+        }
+      }
 #pragma unroll
       for (int u = 0; u < XMAX; ++u) {
-        const int pix = tid / Q + u * STEP;
-        const int pixc = pix < npix ? pix : npix - 1;
-        const int iy = fd_div(pixc, a.fdIW), ix = pixc - iy * a.IW;
-        const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
-        const bool inside = pix < npix && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-        const int gyc = gy < 0 ? 0 : (gy < a.H ? gy : a.H - 1), gxc = gx < 0 ? 0 : (gx < a.W ? gx : a.W - 1);
-        okmask |= (inside ? 1u : 0u) << u;
-        const int off = ((ti.n * a.H + gyc) * a.W + gxc) * a.Cin + 4 * q;      // 32-bit: the host checks that the tensors stay below 2^31 elements
-        px[u] = ld4(a.in + off);
-        if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
+        px[u] = ld4b(a.in, bo[u]);
+        if (TWO) pa[TWO ? u : 0] = ld4b(a.in_aux, bo[u]);
       }
     }
   };
@@ -129,11 +201,41 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
   const bool skip16 = KIND == KIND_TMERGED && WM == 4 && a.Cout == 16 && !(a.flags & RCV_F_DBG_NOSKIP);
   const bool skip8 = KIND == KIND_TMERGED && WM == 2 && a.Cout == 8 && !(a.flags & RCV_F_DBG_NOSKIP);
   const int aoff = l4 * WS + l15;
+
+  // ---- lane constants of the output pixel blocks: LDS offset of the block's pixel, its row / column inside the tile (row 2^24 for the
+  // slots past the tile: never stored) and its byte offset relative to the tile's first output pixel
+  int pixoff[WN], tyb[WN], txb[WN];
+  uint32_t ob[WN];
+#pragma unroll
+  for (int b = 0; b < WN; ++b) {
+    const int p = (wave * WN + b) * 16 + l15;
+    int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
+    const bool used = ty < a.R;
+    if (!used) { ty = 0; tx = 0; }
+    pixoff[b] = ((ty * IS) * a.IW + tx * IS) * S + l4;
+    tyb[b] = used ? ty : (1 << 24);
+    txb[b] = tx;
+    ob[b] = (uint32_t)((KIND == KIND_GATHER ? ty * a.Wo + tx : 2 * (ty * a.Wo + tx)) * a.Cout) * 4u;
+  }
+  uint32_t om[WM];
+  bool cok[WM];
+#pragma unroll
+  for (int m = 0; m < WM; ++m) {
+    const int cov = m * 16 + 4 * l4;
+    cok[m] = cov < a.CoutV;
+    if (KIND == KIND_TMERGED) {
+      const int ph = cov / a.Cout, co = cov - ph * a.Cout;
+      om[m] = (uint32_t)((((ph >> 1) * a.Wo + (ph & 1)) * a.Cout) + co) * 4u;
+    } else {
+      om[m] = (uint32_t)cov * 4u;
+    }
+  }
+
   int tile = xcd_remap(blockIdx.x, gridDim.x);     // neighbouring tiles (shared halo rows) stay on one XCD
-  if (tile < a.total_tiles) prefetch(tile);
+  NarrowTile cur = narrow_decode<KIND>(a, tile < a.total_tiles ? tile : 0);
+  if (tile < a.total_tiles) prefetch(cur);
 
   while (tile < a.total_tiles) {
-    const TileInfo ti = decode_tile<KIND>(a, tile, COT);
     // every wave is done reading the previous tile (and the filter is in place).  Bare barriers in this loop: the fence of
     // __syncthreads() would drain vmcnt, i.e. wait for the prefetch (and for the previous tile's output stores).
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -141,33 +243,26 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
     if (a.flags & RCV_F_DBG_NOSTAGE) {
       // profiling ablation: no LDS writes (the prefetch loads below are still issued: they are unconditional)
     } else if (TWO) {
-      if (a.in_mode == RCV_LOAD_GRAD_ENC) narrow_write_x<RCV_LOAD_GRAD_ENC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid);
-      else narrow_write_x<RCV_LOAD_GRAD_DEC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid);
+      if (a.in_mode == RCV_LOAD_GRAD_ENC) narrow_write_x<RCV_LOAD_GRAD_ENC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, cur.interior, tid);
+      else narrow_write_x<RCV_LOAD_GRAD_DEC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, cur.interior, tid);
     } else {
       switch (a.in_mode) {
-        case RCV_LOAD_PLAIN: narrow_write_x<RCV_LOAD_PLAIN, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid); break;
-        case RCV_LOAD_AFFINE: narrow_write_x<RCV_LOAD_AFFINE, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid); break;
-        case RCV_LOAD_AFFINE_RELU: narrow_write_x<RCV_LOAD_AFFINE_RELU, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid); break;
-        default: narrow_write_x<RCV_LOAD_NCHW, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, tid); break;
+        case RCV_LOAD_PLAIN: narrow_write_x<RCV_LOAD_PLAIN, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, cur.interior, tid); break;
+        case RCV_LOAD_AFFINE: narrow_write_x<RCV_LOAD_AFFINE, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, cur.interior, tid); break;
+        case RCV_LOAD_AFFINE_RELU: narrow_write_x<RCV_LOAD_AFFINE_RELU, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, cur.interior, tid); break;
+        default: narrow_write_x<RCV_LOAD_NCHW, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, false, tid); break;
       }
     }
     const int ntile = tile + gridDim.x;
     // next tile's loads: in flight during the contraction and the stores below.  Unconditional (the last iteration re-requests its
     // own tile, L2 hits): behind a branch the compiler parks a vmcnt(0) in front of the contraction where the two paths meet.
-    prefetch(ntile < a.total_tiles ? ntile : tile);
+    const NarrowTile nxt = narrow_decode<KIND>(a, ntile < a.total_tiles ? ntile : tile);
+    prefetch(nxt);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
     // ---- contraction
-    if (a.flags & RCV_F_DBG_NOMFMA) { tile = ntile; continue; }      // profiling ablation
-    int pixoff[WN];
-#pragma unroll
-    for (int b = 0; b < WN; ++b) {
-      const int p = (wave * WN + b) * 16 + l15;
-      int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
-      if (ty >= a.R) { ty = 0; tx = 0; }
-      pixoff[b] = ((ty * IS) * a.IW + tx * IS) * S + l4;
-    }
+    if (a.flags & RCV_F_DBG_NOMFMA) { tile = ntile; cur = nxt; continue; }      // profiling ablation
     f32x4 acc[WM][WN];
 #pragma unroll
     for (int m = 0; m < WM; ++m)
@@ -199,84 +294,97 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
       }
     }
 
-    // ---- stores + statistics of this tile (statistics stay in registers)
+    // ---- stores + statistics of this tile (statistics stay in registers).  Per block: two compares against the tile's limits, one
+    // address add; everything else about a block's position is a lane constant.  The statistics kind, the residual flag and the ReLU flag select one
+    // of sixteen straight-line copies of the epilogue per TILE (uniform branch): as run-time tests inside the block loop they cost a
+    // register shuffle per block where the variants met again.
+    bool pv[WN];
 #pragma unroll
-    for (int m = 0; m < WM; ++m) {
-      const int cov = m * 16 + 4 * l4;
-      int co = cov, py = 0, pxx = 0;
-      if (KIND == KIND_TMERGED) { const int ph = cov / a.Cout; co = cov - ph * a.Cout; py = ph >> 1; pxx = ph & 1; }
-      const bool co_ok = cov < a.CoutV;
-      float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 e0 = bias, e1 = bias, mu = bias;
-      if (co_ok) {
-        if (a.flags & RCV_F_BIAS) bias = ld4(a.bias + co);
-        if (a.stats == RCV_STATS_BWD_DEC) { e0 = ld4(a.epi_c + co); e1 = ld4(a.epi_c + a.Cout + co); }
-        if (a.stats == RCV_STATS_BWD_DEC || a.stats == RCV_STATS_BWD_ENC) mu = ld4(a.epi_c + 2 * a.Cout + co);
-      }
-      // first the loads of the skip gradient / statistics operand of (a group of) the pixel blocks of this co-block (independent, in
-      // flight together), then the arithmetic and the stores.  Groups of at most BG blocks: with all five of the widest two-tensor tiles
-      // in one batch the kernel needed > 256 registers and the compiler parked part of the PREFETCHED input tile in scratch, i.e.
-      // waited for those loads right after issuing them
-      constexpr int BG = !TWO ? WN : (WN > 3 ? 3 : (WM >= 4 ? 2 : WN));
-      const bool need_e = a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC;
+    for (int b = 0; b < WN; ++b) pv[b] = tyb[b] < cur.rlim && txb[b] < cur.wlim;
+    auto epilogue = [&](auto stats_c, auto resid_c, auto relu_c) {
+      constexpr int STATS = decltype(stats_c)::value;
+      constexpr bool RESID = decltype(resid_c)::value;
+      constexpr bool RELU = decltype(relu_c)::value;
+      constexpr bool NEED_E = STATS == RCV_STATS_BWD_ENC || STATS == RCV_STATS_BWD_DEC;
 #pragma unroll
-      for (int b0 = 0; b0 < WN; b0 += BG) {
-      int offs[BG];
-      bool oks[BG];
-      float4 rr[BG], ee[BG];
-#pragma unroll
-      for (int bb = 0; bb < BG; ++bb) {
-        const int b = b0 + bb;
-        if (b >= WN) { oks[bb] = false; offs[bb] = 0; rr[bb] = make_float4(0.f, 0.f, 0.f, 0.f); ee[bb] = rr[bb]; continue; }
-        const int p = (wave * WN + b) * 16 + l15;
-        const int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
-        int oy = ti.y0 + ty, ox = ti.x0 + tx;
-        bool ok = ty < a.R && co_ok;
-        if (KIND != KIND_GATHER) {
-          ok = ok && oy < a.H && ox < a.W;
-          oy = 2 * oy + py; ox = 2 * ox + pxx;
-        } else {
-          ok = ok && oy < a.Ho && ox < a.Wo;
+      for (int m = 0; m < WM; ++m) {
+        const float4 bias = *reinterpret_cast<const float4*>(ec + 0 * COT + m * 16 + 4 * l4);
+        float4 e0 = bias, e1 = bias, mu = bias;
+        if (STATS == RCV_STATS_BWD_DEC) {
+          e0 = *reinterpret_cast<const float4*>(ec + 1 * COT + m * 16 + 4 * l4);
+          e1 = *reinterpret_cast<const float4*>(ec + 2 * COT + m * 16 + 4 * l4);
         }
-        oks[bb] = ok;
-        offs[bb] = ((ti.n * a.Ho + oy) * a.Wo + ox) * a.Cout + co;
-        rr[bb] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ee[bb] = rr[bb];
-        if (ok) {
-          if (a.flags & RCV_F_RESID) rr[bb] = ld4(a.resid + offs[bb]);
-          if (need_e) ee[bb] = ld4(a.epi_aux + offs[bb]);
-        }
-      }
+        if (NEED_E) mu = *reinterpret_cast<const float4*>(ec + 3 * COT + m * 16 + 4 * l4);
+        const uint32_t omt = cur.obase + om[m];
+        // first the loads of the skip gradient / statistics operand of (a group of) the pixel blocks of this co-block (independent, in
+        // flight together), then the arithmetic and the stores.  Groups of at most BG blocks: with all five of the widest two-tensor
+        // tiles in one batch the kernel needed > 256 registers and the compiler parked part of the PREFETCHED input tile in scratch,
+        // i.e. waited for those loads right after issuing them
+        constexpr int BG = !TWO ? WN : (WN > 3 ? 3 : (WM >= 4 ? 2 : WN));
 #pragma unroll
-      for (int bb = 0; bb < BG; ++bb) {
-        const int b = b0 + bb;
-        if (b >= WN || !oks[bb]) continue;
-        float4 v = make_float4(acc[m][b][0] + bias.x, acc[m][b][1] + bias.y, acc[m][b][2] + bias.z, acc[m][b][3] + bias.w);
-        if (a.flags & RCV_F_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        v.x += rr[bb].x; v.y += rr[bb].y; v.z += rr[bb].z; v.w += rr[bb].w;
-        *reinterpret_cast<float4*>(a.out + offs[bb]) = v;
-        const float4 e = ee[bb];
-        if (a.stats == RCV_STATS_FWD) {
-          s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
-          s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
-          s2[m][2] = fmaf(v.z, v.z, s2[m][2]); s2[m][3] = fmaf(v.w, v.w, s2[m][3]);
-        } else if (a.stats == RCV_STATS_BWD_ENC) {
-          s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
-          s2[m][0] = fmaf(v.x, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(v.y, e.y - mu.y, s2[m][1]);
-          s2[m][2] = fmaf(v.z, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(v.w, e.w - mu.w, s2[m][3]);
-        } else if (a.stats == RCV_STATS_BWD_DEC) {
-          const float gx = fmaf(e.x, e0.x, e1.x) > 0.f ? v.x : 0.f;
-          const float gy = fmaf(e.y, e0.y, e1.y) > 0.f ? v.y : 0.f;
-          const float gz = fmaf(e.z, e0.z, e1.z) > 0.f ? v.z : 0.f;
-          const float gw = fmaf(e.w, e0.w, e1.w) > 0.f ? v.w : 0.f;
-          s1[m][0] += gx; s1[m][1] += gy; s1[m][2] += gz; s1[m][3] += gw;
-          s2[m][0] = fmaf(gx, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(gy, e.y - mu.y, s2[m][1]);
-          s2[m][2] = fmaf(gz, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(gw, e.w - mu.w, s2[m][3]);
+        for (int b0 = 0; b0 < WN; b0 += BG) {
+          float4 rr[BG], ee[BG];
+          if (RESID || NEED_E) {
+#pragma unroll
+            for (int bb = 0; bb < BG; ++bb) {
+              const int b = b0 + bb;
+              if (b < WN && pv[b] && cok[m]) {
+                if (RESID) rr[bb] = ld4b(a.resid, omt + ob[b]);
+                if (NEED_E) ee[bb] = ld4b(a.epi_aux, omt + ob[b]);
+              }
+            }
+          }
+#pragma unroll
+          for (int bb = 0; bb < BG; ++bb) {
+            const int b = b0 + bb;
+            if (b >= WN || !(pv[b] && cok[m])) continue;
+            float4 v = make_float4(acc[m][b][0] + bias.x, acc[m][b][1] + bias.y, acc[m][b][2] + bias.z, acc[m][b][3] + bias.w);
+            if (RELU) {     // one v_med3_f32 per element (fmaxf costs a canonicalising v_max first); NaN -> 0 like fmaxf(NaN, 0)
+              const float inf = __builtin_inff();
+              v.x = __builtin_amdgcn_fmed3f(v.x, 0.f, inf); v.y = __builtin_amdgcn_fmed3f(v.y, 0.f, inf);
+              v.z = __builtin_amdgcn_fmed3f(v.z, 0.f, inf); v.w = __builtin_amdgcn_fmed3f(v.w, 0.f, inf);
+            }
+            if (RESID) { v.x += rr[bb].x; v.y += rr[bb].y; v.z += rr[bb].z; v.w += rr[bb].w; }
+            st4b(a.out, omt + ob[b], v);
+            if (STATS == RCV_STATS_FWD) {
+              s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+              s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
+              s2[m][2] = fmaf(v.z, v.z, s2[m][2]); s2[m][3] = fmaf(v.w, v.w, s2[m][3]);
+            } else if (STATS == RCV_STATS_BWD_ENC) {
+              const float4 e = ee[bb];
+              s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+              s2[m][0] = fmaf(v.x, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(v.y, e.y - mu.y, s2[m][1]);
+              s2[m][2] = fmaf(v.z, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(v.w, e.w - mu.w, s2[m][3]);
+            } else if (STATS == RCV_STATS_BWD_DEC) {
+              const float4 e = ee[bb];
+              const float gx = fmaf(e.x, e0.x, e1.x) > 0.f ? v.x : 0.f;
+              const float gy = fmaf(e.y, e0.y, e1.y) > 0.f ? v.y : 0.f;
+              const float gz = fmaf(e.z, e0.z, e1.z) > 0.f ? v.z : 0.f;
+              const float gw = fmaf(e.w, e0.w, e1.w) > 0.f ? v.w : 0.f;
+              s1[m][0] += gx; s1[m][1] += gy; s1[m][2] += gz; s1[m][3] += gw;
+              s2[m][0] = fmaf(gx, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(gy, e.y - mu.y, s2[m][1]);
+              s2[m][2] = fmaf(gz, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(gw, e.w - mu.w, s2[m][3]);
+            }
+          }
         }
       }
-      }
+    };
+    auto epilogue_f = [&](auto stats_c, auto resid_c) {
+      if (a.flags & RCV_F_RELU) epilogue(stats_c, resid_c, std::integral_constant<bool, true>{});
+      else epilogue(stats_c, resid_c, std::integral_constant<bool, false>{});
+    };
+    auto epilogue_r = [&](auto stats_c) {
+      if (a.flags & RCV_F_RESID) epilogue_f(stats_c, std::integral_constant<bool, true>{});
+      else epilogue_f(stats_c, std::integral_constant<bool, false>{});
+    };
+    switch (a.stats) {
+      case RCV_STATS_FWD: epilogue_r(std::integral_constant<int, RCV_STATS_FWD>{}); break;
+      case RCV_STATS_BWD_ENC: epilogue_r(std::integral_constant<int, RCV_STATS_BWD_ENC>{}); break;
+      case RCV_STATS_BWD_DEC: epilogue_r(std::integral_constant<int, RCV_STATS_BWD_DEC>{}); break;
+      default: epilogue_r(std::integral_constant<int, RCV_STATS_NONE>{}); break;
     }
     tile = ntile;
+    cur = nxt;
   }
 
   // ---- one statistics row per workgroup
@@ -327,8 +435,11 @@ static inline bool narrow_wn_built(int WN, int CK, int WM) {
 }
 
 bool convs_supported(const rcv_handle* h, const rcv_op* op, int kind, int CinP, int CoutV) {
-  (void)h; (void)op;
+  (void)h;
   if (RCV_ENV("RCV_NO_NARROW")) return false;
+  // 32-bit byte offsets from the tensor bases: input and output stay below 4 GiB
+  if ((long long)op->i[RCV_I_N] * op->i[RCV_I_H] * op->i[RCV_I_W] * op->i[RCV_I_CIN] >= (1ll << 30)) return false;
+  if ((long long)op->i[RCV_I_N] * op->i[RCV_I_HO] * op->i[RCV_I_WO] * op->i[RCV_I_COUT] >= (1ll << 30)) return false;
   if (kind == KIND_TPHASE) return false;
   if (!(CinP == 4 || CinP == 8 || CinP == 16 || CinP == 32)) return false;
   if (kind == KIND_TMERGED && (CinP == 16 || CinP == 32) && round_up(CoutV, 16) == 64 && !RCV_ENV("RCV_NO_NARROW4")) return true;   // 4 x 16 virtual channels
@@ -384,7 +495,7 @@ int convs_make_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* p
   const int S = conv_xpitch(CinP, kind == KIND_GATHER ? s : 1);
   pl->wl_floats = round_up(ntaps * CinP * (pl->CoutP + 16), 4);
   pl->xl_floats = round_up(pl->IH * pl->IW * S, 4);
-  const size_t floats = (size_t)pl->wl_floats + pl->xl_floats + 5 * CinP + 16 + (size_t)4 * 2 * pl->CoutP;
+  const size_t floats = (size_t)pl->wl_floats + pl->xl_floats + 5 * CinP + 16 + (size_t)4 * 2 * pl->CoutP + (size_t)4 * pl->CoutP;
   pl->lds = floats * sizeof(float);
   RCV_CHECK_ARG(pl->lds <= (size_t)h->max_lds, "conv (narrow): tile needs %zu B of LDS", pl->lds);
   pl->n_co_tiles = 1; pl->n_phases = 1;
