@@ -27,11 +27,13 @@ __device__ __forceinline__ void st4b(float* base, uint32_t byte_off, float4 v) {
   *reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off) = v;
 }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
 // Per-tile scalars of the persistent loop (all uniform: they live in SGPRs)
 struct NarrowTile {
   int n, oy0, ox0;          // image, first staged input row / column (may be negative: padding)
   uint32_t obase;           // byte offset of the tile's first output pixel (channel 0)
-  int rlim, wlim;           // output rows / columns of the tile that lie inside the plane
+  uint32_t lim;             // (output rows of the tile inside the plane - 1) << 16 | (output columns inside the plane - 1)
   bool interior;            // the whole staged input tile lies inside the plane: no padding, no per-pixel bounds work
 };
 
@@ -45,11 +47,11 @@ __device__ __forceinline__ NarrowTile narrow_decode(const ConvArgs& a, int t) {
   if (KIND == KIND_GATHER) {
     ti.oy0 = y0 * a.stride - a.dil; ti.ox0 = x0 * a.stride - a.dil;
     ti.obase = (uint32_t)(((ti.n * a.Ho + y0) * a.Wo + x0) * a.Cout) * 4u;
-    ti.rlim = a.Ho - y0; ti.wlim = a.Wo - x0;
+    ti.lim = (uint32_t)(a.Ho - y0 - 1) << 16 | (uint32_t)(a.Wo - x0 - 1);
   } else {
     ti.oy0 = y0; ti.ox0 = x0;
     ti.obase = (uint32_t)(((ti.n * a.Ho + 2 * y0) * a.Wo + 2 * x0) * a.Cout) * 4u;
-    ti.rlim = a.H - y0; ti.wlim = a.W - x0;
+    ti.lim = (uint32_t)(a.H - y0 - 1) << 16 | (uint32_t)(a.W - x0 - 1);
   }
   ti.interior = ti.oy0 >= 0 && ti.ox0 >= 0 && ti.oy0 + a.IH <= a.H && ti.ox0 + a.IW <= a.W;
   return ti;
@@ -128,9 +130,10 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
   }
 
   // ---- lane constants of the staging slots (the same for every tile): position inside the staged tile, byte offset relative to the
-  // tile's first input pixel.  Slots past the tile sit at row 2^24: never inside the plane.
+  // tile's first input pixel.  Slots past the tile sit at row 32767: never inside the plane
+  // (the host keeps H below 16384 for this kernel).
   const int q = tid % Q, lpix = tid / Q;
-  int siy[XMAX], six[XMAX];
+  uint32_t sxy[XMAX];                      // row << 16 | column
   uint32_t rel4[XMAX];
   uint32_t slotmask = 0;
 #pragma unroll
@@ -138,8 +141,7 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
     const int pix = lpix + u * STEP;
     const int pixc = pix < npix ? pix : npix - 1;
     const int iy = fd_div(pixc, a.fdIW), ix = pixc - iy * a.IW;
-    siy[u] = pix < npix ? iy : (1 << 24);
-    six[u] = ix;
+    sxy[u] = (uint32_t)(pix < npix ? iy : 0x7fff) << 16 | (uint32_t)ix;
     rel4[u] = (uint32_t)((iy * a.W + ix) * a.Cin + 4 * q) * 4u;
     slotmask |= (pix < npix ? 1u : 0u) << u;
   }
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int u = 0; u < XMAX; ++u) {
         px[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int gy = ti.oy0 + siy[u], gx = ti.ox0 + six[u];
+        const int gy = ti.oy0 + (int)(sxy[u] >> 16), gx = ti.ox0 + (int)(sxy[u] & 0xffffu);
         if (Q == 1 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
           okmask |= 1u << u;
           const size_t plane = (size_t)a.H * a.W;
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
         okmask = 0;
 #pragma unroll
         for (int u = 0; u < XMAX; ++u) {
-          const bool inside = (unsigned)(ti.oy0 + siy[u]) < (unsigned)a.H && (unsigned)(ti.ox0 + six[u]) < (unsigned)a.W;
+          const bool inside = (unsigned)(ti.oy0 + (int)(sxy[u] >> 16)) < (unsigned)a.H && (unsigned)(ti.ox0 + (int)(sxy[u] & 0xffffu)) < (unsigned)a.W;
           okmask |= (inside ? 1u : 0u) << u;
           bo[u] = inside ? tb4 + rel4[u] : 0u;
         }
@@ -202,9 +204,10 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
   const bool skip8 = KIND == KIND_TMERGED && WM == 2 && a.Cout == 8 && !(a.flags & RCV_F_DBG_NOSKIP);
   const int aoff = l4 * WS + l15;
 
-  // ---- lane constants of the output pixel blocks: LDS offset of the block's pixel, its row / column inside the tile (row 2^24 for the
+  // ---- lane constants of the output pixel blocks: LDS offset of the block's pixel, its row / column inside the tile (row 65535 for the
   // slots past the tile: never stored) and its byte offset relative to the tile's first output pixel
-  int pixoff[WN], tyb[WN], txb[WN];
+  int pixoff[WN];
+  uint32_t tyx[WN];                        // row << 16 | column
   uint32_t ob[WN];
 #pragma unroll
   for (int b = 0; b < WN; ++b) {
@@ -213,8 +216,7 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
     const bool used = ty < a.R;
     if (!used) { ty = 0; tx = 0; }
     pixoff[b] = ((ty * IS) * a.IW + tx * IS) * S + l4;
-    tyb[b] = used ? ty : (1 << 24);
-    txb[b] = tx;
+    tyx[b] = (uint32_t)(used ? ty : 0xffff) << 16 | (uint32_t)tx;
     ob[b] = (uint32_t)((KIND == KIND_GATHER ? ty * a.Wo + tx : 2 * (ty * a.Wo + tx)) * a.Cout) * 4u;
   }
   uint32_t om[WM];
@@ -263,51 +265,91 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
 
     // ---- contraction
     if (a.flags & RCV_F_DBG_NOMFMA) { tile = ntile; cur = nxt; continue; }      // profiling ablation
+    // the tile's limits against the lane constants of the pixel blocks: which blocks this tile stores
+    bool pv[WN];
+#pragma unroll
+    for (int b = 0; b < WN; ++b) {       // row < rlim && column < wlim as one packed 16-bit minimum and one compare
+      const u16x2 t = __builtin_bit_cast(u16x2, tyx[b]);
+      pv[b] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(t, __builtin_bit_cast(u16x2, cur.lim))) == tyx[b];
+    }
+    // The statistics operand of the gradient variants (one 16-byte piece of the saved activation per output pixel and lane) is
+    // requested HERE, before the contraction, for the first EROWS channel blocks: requested in the epilogue it put a full HBM round
+    // trip per block group on the critical path of every tile (two waves per SIMD cannot hide it), which made the gradient variants
+    // 1.5-2x slower than the forward ones.  Branch-free: a block that is not stored reads byte 0.
+    constexpr int EROWS = !TWO ? 0 : (WM * WN <= 6 ? WM : (WM * WN < 10 ? 1 : 0));      // (the widest tiles have no registers left for it)
+    float4 ee_early[EROWS ? EROWS : 1][WN];
+    if (TWO && need_e) {
+#pragma unroll
+      for (int m = 0; m < EROWS; ++m)
+#pragma unroll
+        for (int b = 0; b < WN; ++b) ee_early[m][b] = ld4b(a.epi_aux, (pv[b] && cok[m]) ? cur.obase + om[m] + ob[b] : 0u);
+    }
+    constexpr bool TIGHT = TWO || (KIND == KIND_GATHER && WM * WN >= 10);
     f32x4 acc[WM][WN];
 #pragma unroll
     for (int m = 0; m < WM; ++m)
 #pragma unroll
       for (int b = 0; b < WN; ++b) acc[m][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // SC: LDS pitch of a staged pixel as a compile-time constant (dilation 1): the tap's column offset and the k-step are then immediate
+    // offsets of the LDS reads and a pixel block needs one address register per tap ROW instead of one per tap (45 -> 15 registers for a
+    // 3x3 filter and five blocks); SC = 0: run-time pitch and dilation
+    auto contract = [&](auto sc_c) {
+      constexpr int SC = decltype(sc_c)::value;
+      // (TIGHT variants: opaque copies -- the compiler would otherwise hoist every (tap, block) address of every variant of this loop
+      // out of the tile loop, 45 + 15 + 15 registers; two dozen adds per tile are the cheaper side of that trade there)
+      int po[WN];
 #pragma unroll
-    for (int j = 0; j < NTAPS; ++j) {
-      const int jy = j / NXT, jx = j % NXT;
-      const int dy = KIND == KIND_GATHER ? jy * a.dil : jy, dx = KIND == KIND_GATHER ? jx * a.dil : jx;
-      const float* wj = wl + j * CK * WS + aoff;
-      const float* xj = xl + (dy * a.IW + dx) * S;
+      for (int b = 0; b < WN; ++b) { po[b] = pixoff[b]; if (TIGHT) asm volatile("" : "+v"(po[b])); }
 #pragma unroll
-      for (int kk = 0; kk < CK / 4; ++kk) {
-        float av[WM], bv[WN];
+      for (int j = 0; j < NTAPS; ++j) {
+        const int jy = j / NXT, jx = j % NXT;
+        const int dy = (KIND == KIND_GATHER && SC == 0) ? jy * a.dil : jy, dx = (KIND == KIND_GATHER && SC == 0) ? jx * a.dil : jx;
+        const float* wj = wl + j * CK * WS + aoff;
+        const float* xj = SC ? xl + dy * a.IW * SC + jx * SC : xl + (dy * a.IW + dx) * S;
 #pragma unroll
-        for (int m = 0; m < WM; ++m) av[m] = wj[kk * 4 * WS + m * 16];
+        for (int kk = 0; kk < CK / 4; ++kk) {
+          float av[WM], bv[WN];
 #pragma unroll
-        for (int b = 0; b < WN; ++b) bv[b] = xj[pixoff[b] + kk * 4];
+          for (int m = 0; m < WM; ++m) av[m] = wj[kk * 4 * WS + m * 16];
 #pragma unroll
-        for (int m = 0; m < WM; ++m) {
-          // merged transposed conv: the filter block of output parity (py,px) is structurally zero for the window taps with
-          // dy > py or dx > px (7 of the 16 (parity, tap) pairs).  Where a 16-channel block holds whole parities the MFMAs on
-          // those blocks are skipped: Cout = 16 -> block m is parity m; Cout = 8 -> block m holds both px of py = m.
-          if (KIND == KIND_TMERGED && ((skip16 && (jy > (m >> 1) || jx > (m & 1))) || (skip8 && jy > m))) continue;
+          for (int b = 0; b < WN; ++b) bv[b] = xj[po[b] + kk * 4];
 #pragma unroll
-          for (int b = 0; b < WN; ++b)
-            acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[m][b], 0, 0, 0);
+          for (int m = 0; m < WM; ++m) {
+            // merged transposed conv: the filter block of output parity (py,px) is structurally zero for the window taps with
+            // dy > py or dx > px (7 of the 16 (parity, tap) pairs).  Where a 16-channel block holds whole parities the MFMAs on
+            // those blocks are skipped: Cout = 16 -> block m is parity m; Cout = 8 -> block m holds both px of py = m.
+            if (KIND == KIND_TMERGED && ((skip16 && (jy > (m >> 1) || jx > (m & 1))) || (skip8 && jy > m))) continue;
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+              acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[m][b], 0, 0, 0);
+          }
         }
       }
+    };
+    if constexpr (TIGHT) {
+      // the gradient variants need the registers (both operand tensors of the next tile and the statistics operand are in flight),
+      // and so do the 3x3 variants with ten accumulator blocks
+      const bool unit_dil = KIND != KIND_GATHER || a.dil == 1;
+      if (unit_dil && S == CK + 2) contract(std::integral_constant<int, CK + 2>{});
+      else if (unit_dil && S == CK + 1) contract(std::integral_constant<int, CK + 1>{});
+      else contract(std::integral_constant<int, 0>{});
+    } else {
+      // the other one-tensor variants: register room to spare, every (tap, block) address stays hoisted (no address arithmetic per tile)
+      contract(std::integral_constant<int, 0>{});
     }
 
     // ---- stores + statistics of this tile (statistics stay in registers).  Per block: two compares against the tile's limits, one
     // address add; everything else about a block's position is a lane constant.  The statistics kind, the residual flag and the ReLU flag select one
     // of sixteen straight-line copies of the epilogue per TILE (uniform branch): as run-time tests inside the block loop they cost a
     // register shuffle per block where the variants met again.
-    bool pv[WN];
-#pragma unroll
-    for (int b = 0; b < WN; ++b) pv[b] = tyb[b] < cur.rlim && txb[b] < cur.wlim;
     auto epilogue = [&](auto stats_c, auto resid_c, auto relu_c) {
       constexpr int STATS = decltype(stats_c)::value;
       constexpr bool RESID = decltype(resid_c)::value;
       constexpr bool RELU = decltype(relu_c)::value;
       constexpr bool NEED_E = STATS == RCV_STATS_BWD_ENC || STATS == RCV_STATS_BWD_DEC;
-#pragma unroll
-      for (int m = 0; m < WM; ++m) {
+      auto row = [&](auto m_c) {
+        constexpr int m = decltype(m_c)::value;
+        constexpr bool EARLY = TWO && NEED_E && m < EROWS;        // statistics operand already requested before the contraction
         const float4 bias = *reinterpret_cast<const float4*>(ec + 0 * COT + m * 16 + 4 * l4);
         float4 e0 = bias, e1 = bias, mu = bias;
         if (STATS == RCV_STATS_BWD_DEC) {
@@ -320,17 +362,17 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
         // flight together), then the arithmetic and the stores.  Groups of at most BG blocks: with all five of the widest two-tensor
         // tiles in one batch the kernel needed > 256 registers and the compiler parked part of the PREFETCHED input tile in scratch,
         // i.e. waited for those loads right after issuing them
-        constexpr int BG = !TWO ? WN : (WN > 3 ? 3 : (WM >= 4 ? 2 : WN));
+        constexpr int BG = (!TWO || EARLY) ? WN : (WN > 3 ? 3 : (WM >= 4 ? 2 : WN));
 #pragma unroll
         for (int b0 = 0; b0 < WN; b0 += BG) {
           float4 rr[BG], ee[BG];
-          if (RESID || NEED_E) {
+          if (RESID || (NEED_E && !EARLY)) {
 #pragma unroll
             for (int bb = 0; bb < BG; ++bb) {
               const int b = b0 + bb;
               if (b < WN && pv[b] && cok[m]) {
                 if (RESID) rr[bb] = ld4b(a.resid, omt + ob[b]);
-                if (NEED_E) ee[bb] = ld4b(a.epi_aux, omt + ob[b]);
+                if (NEED_E && !EARLY) ee[bb] = ld4b(a.epi_aux, omt + ob[b]);
               }
             }
           }
@@ -346,17 +388,17 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
             }
             if (RESID) { v.x += rr[bb].x; v.y += rr[bb].y; v.z += rr[bb].z; v.w += rr[bb].w; }
             st4b(a.out, omt + ob[b], v);
+            float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NEED_E) e = EARLY ? ee_early[EARLY ? m : 0][b] : ee[bb];
             if (STATS == RCV_STATS_FWD) {
               s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
               s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
               s2[m][2] = fmaf(v.z, v.z, s2[m][2]); s2[m][3] = fmaf(v.w, v.w, s2[m][3]);
             } else if (STATS == RCV_STATS_BWD_ENC) {
-              const float4 e = ee[bb];
               s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
               s2[m][0] = fmaf(v.x, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(v.y, e.y - mu.y, s2[m][1]);
               s2[m][2] = fmaf(v.z, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(v.w, e.w - mu.w, s2[m][3]);
             } else if (STATS == RCV_STATS_BWD_DEC) {
-              const float4 e = ee[bb];
               const float gx = fmaf(e.x, e0.x, e1.x) > 0.f ? v.x : 0.f;
               const float gy = fmaf(e.y, e0.y, e1.y) > 0.f ? v.y : 0.f;
               const float gz = fmaf(e.z, e0.z, e1.z) > 0.f ? v.z : 0.f;
@@ -367,7 +409,10 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
             }
           }
         }
-      }
+      };
+      row(std::integral_constant<int, 0>{});
+      if constexpr (WM > 1) row(std::integral_constant<int, 1>{});
+      if constexpr (WM > 2) { row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{}); }
     };
     auto epilogue_f = [&](auto stats_c, auto resid_c) {
       if (a.flags & RCV_F_RELU) epilogue(stats_c, resid_c, std::integral_constant<bool, true>{});
@@ -437,6 +482,7 @@ static inline bool narrow_wn_built(int WN, int CK, int WM) {
 bool convs_supported(const rcv_handle* h, const rcv_op* op, int kind, int CinP, int CoutV) {
   (void)h;
   if (RCV_ENV("RCV_NO_NARROW")) return false;
+  if (op->i[RCV_I_H] >= 16384 || op->i[RCV_I_W] >= 16384 || op->i[RCV_I_HO] >= 16384 || op->i[RCV_I_WO] >= 16384) return false;   // packed 16-bit tile coordinates
   // 32-bit byte offsets from the tensor bases: input and output stay below 4 GiB
   if ((long long)op->i[RCV_I_N] * op->i[RCV_I_H] * op->i[RCV_I_W] * op->i[RCV_I_CIN] >= (1ll << 30)) return false;
   if ((long long)op->i[RCV_I_N] * op->i[RCV_I_HO] * op->i[RCV_I_WO] * op->i[RCV_I_COUT] >= (1ll << 30)) return false;
