@@ -103,6 +103,11 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int n_part, i
                                    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
                                    float eps, int training, float* consts, float* save_mean, float* save_istd) {
   const int c = blockIdx.x;
+  // the channel's parameters are requested before the partial rows (uniform addresses: scalar loads), not after the reduction: they
+  // miss in L2 once per step and the kernel is nothing but a chain of memory round trips
+  const float g_c = gamma[c], b_c = beta[c];
+  const bool upd = training && running_mean;
+  const float rm_c = upd ? running_mean[c] : 0.f, rv_c = upd ? running_var[c] : 0.f;
   double s1 = 0.0, s2 = 0.0;
   for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
     s1 += (double)part[((size_t)i * 2 + 0) * C + c];
@@ -114,17 +119,17 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int n_part, i
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float istd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * istd;
+    const float sc = g_c * istd;
     consts[0 * C + c] = sc;
-    consts[1 * C + c] = beta[c] - (float)mean * sc;
+    consts[1 * C + c] = b_c - (float)mean * sc;
     consts[2 * C + c] = (float)mean;          // row 2: batch mean (the backward sums are taken about it)
     consts[3 * C + c] = 0.f; consts[4 * C + c] = 0.f;
     save_mean[c] = (float)mean;
     save_istd[c] = istd;
-    if (training && running_mean) {
+    if (upd) {
       const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+      running_mean[c] = (1.f - momentum) * rm_c + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * rv_c + momentum * (float)unbiased;
     }
   }
 }
@@ -147,6 +152,9 @@ __global__ void bn_bwd_kernel(const float* __restrict__ part, int n_part, int C,
                               const float* __restrict__ save_mean, const float* __restrict__ save_istd,
                               const float* __restrict__ fwd_consts, float* consts, float* dgamma, float* dbeta) {
   const int c = blockIdx.x;
+  // (the channel's scalars first, see bn_finalize_kernel)
+  const float mean_c = save_mean[c], istd_c = save_istd[c], g_c = gamma[c];
+  const float f0_c = fwd_consts[0 * C + c], f1_c = fwd_consts[1 * C + c];
   double s1 = 0.0, s2 = 0.0;
   for (int i = threadIdx.x; i < n_part; i += blockDim.x) {
     s1 += (double)part[((size_t)i * 2 + 0) * C + c];
@@ -155,16 +163,16 @@ __global__ void bn_bwd_kernel(const float* __restrict__ part, int n_part, int C,
   block_sum2_d(s1, s2);
   if (threadIdx.x == 0) {
     // s2 arrives centred: sum g*(r - mean) (accumulated about the batch mean to avoid cancellation)
-    const double mean = save_mean[c], istd = save_istd[c];
+    const double mean = mean_c, istd = istd_c;
     const double sgx = istd * s2;
-    const double A = (double)gamma[c] * istd;
+    const double A = (double)g_c * istd;
     const double Cc = -A * istd * sgx / count;
     const double B = -A * s1 / count - Cc * mean;
     consts[0 * C + c] = (float)A;
     consts[1 * C + c] = (float)B;
     consts[2 * C + c] = (float)Cc;
-    consts[3 * C + c] = fwd_consts[0 * C + c];
-    consts[4 * C + c] = fwd_consts[1 * C + c];
+    consts[3 * C + c] = f0_c;
+    consts[4 * C + c] = f1_c;
     if (dgamma) dgamma[c] = (float)sgx;
     if (dbeta) dbeta[c] = (float)s1;
   }
