@@ -41,20 +41,36 @@ __device__ __forceinline__ void wstage_tile(const float* __restrict__ src, const
 #pragma unroll
     for (int j = 0; j < 5; ++j) k[j] = ch_ok ? wld4(consts + (size_t)j * C + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // A thread's slots are `step` tile pixels apart: its tile coordinates, its tensor offset and its LDS address advance by constants
+  // (with one carry into the next tile row), instead of a division, two multiply-adds and a multiply per element; a tile that lies
+  // inside the plane (the common case) needs no bounds tests either.  Next to MFMAs every vector instruction costs matrix-pipe time.
+  const int lp = tid / Q;
   const int step = nthreads / Q;
-  for (int pix0 = tid / Q; pix0 < npix; pix0 += UNR * step) {
+  const int dqy = fd_div(step, fdTW), dqx = step - dqy * TW;             // (uniform)
+  const int nrows = fd_div(npix, fdTW);                                  // npix is a whole number of tile rows
+  const bool interior = TW == TWV && oy >= 0 && ox >= 0 && oy + nrows <= PH && ox + TW <= PW;
+  int iy = fd_div(lp, fdTW), ix = lp - iy * TW;
+  uint32_t off = (uint32_t)(((row0 + oy + iy) * PW + ox + ix) * C + ch);  // element offset of the slot (modulo 2^32 while the slot is outside the plane)
+  const uint32_t d_off = (uint32_t)((dqy * PW + dqx) * C), w_off = (uint32_t)((PW - TW) * C);
+  float* dst = lds + lp * S + 4 * q;
+  const int d_dst = step * S;
+  for (int pix0 = lp; pix0 < npix; pix0 += UNR * step) {
     float4 x[UNR], ax[UNR];
     bool ok[UNR];
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
       const int pix = pix0 + u * step;
-      const int iy = fd_div(pix, fdTW), ix = pix - iy * TW;
-      const int gy = oy + iy, gx = ox + ix;
-      ok[u] = ch_ok && pix < npix && ix < TWV && (unsigned)gy < (unsigned)PH && (unsigned)gx < (unsigned)PW;
-      const int off = ok[u] ? ((row0 + gy) * PW + gx) * C + ch : 0;
-      x[u] = wld4(src + off);
-      if (TWO) ax[u] = wld4(aux + off);
+      if (interior) ok[u] = ch_ok && pix < npix;
+      else ok[u] = ch_ok && pix < npix && ix < TWV && (unsigned)(oy + iy) < (unsigned)PH && (unsigned)(ox + ix) < (unsigned)PW;
+      const uint32_t o = ok[u] ? off : 0u;
+      x[u] = wld4(src + o);
+      if (TWO) ax[u] = wld4(aux + o);
       else ax[u] = x[u];
+      ix += dqx; off += d_off;
+      const bool carry = ix >= TW;
+      ix -= carry ? TW : 0;
+      off += carry ? w_off : 0u;
+      if (!interior) iy += dqy + (carry ? 1 : 0);
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -63,10 +79,10 @@ __device__ __forceinline__ void wstage_tile(const float* __restrict__ src, const
       if (!ok[u]) v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (SUM) { sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w; }
       if (pix < npix) {
-        float* dst = lds + pix * S + 4 * q;
         if (SCALAR_STORE) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
         else *reinterpret_cast<float4*>(dst) = v;
       }
+      dst += d_dst;
     }
   }
 }
