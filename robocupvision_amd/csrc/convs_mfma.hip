@@ -29,6 +29,15 @@ __device__ __forceinline__ void st4b(float* base, uint32_t byte_off, float4 v) {
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+#ifdef RCV_STAMPS
+// diagnostic build only (make STAMPS=1): shader-clock stamps around the phases of the tile loop, summed per wave
+// (scripts/bench_op.py --stamps 1 prints them)
+#define RCVS_STAMP(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define RCVS_SEG(k) do { RCVS_STAMP(st_b); st_seg[k] += st_b - st_a; st_a = st_b; } while (0)
+#else
+#define RCVS_SEG(k) do { } while (0)
+#endif
+
 // Per-tile scalars of the persistent loop (all uniform: they live in SGPRs)
 struct NarrowTile {
   int n, oy0, ox0;          // image, first staged input row / column (may be negative: padding)
@@ -233,15 +242,24 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
     }
   }
 
+#ifdef RCV_STAMPS
+  unsigned long long st_k0 = 0, st_a = 0, st_b = 0, st_seg[6] = {0, 0, 0, 0, 0, 0}, st_loop0 = 0, st_loop1 = 0;
+  const unsigned long long st_rt0 = __builtin_amdgcn_s_memrealtime();
+  RCVS_STAMP(st_k0);
+#endif
   int tile = xcd_remap(blockIdx.x, gridDim.x);     // neighbouring tiles (shared halo rows) stay on one XCD
   NarrowTile cur = narrow_decode<KIND>(a, tile < a.total_tiles ? tile : 0);
   if (tile < a.total_tiles) prefetch(cur);
 
+#ifdef RCV_STAMPS
+  RCVS_STAMP(st_loop0); st_a = st_loop0;
+#endif
   while (tile < a.total_tiles) {
     // every wave is done reading the previous tile (and the filter is in place).  Bare barriers in this loop: the fence of
     // __syncthreads() would drain vmcnt, i.e. wait for the prefetch (and for the previous tile's output stores).
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    RCVS_SEG(0);
     if (a.flags & RCV_F_DBG_NOSTAGE) {
       // profiling ablation: no LDS writes (the prefetch loads below are still issued: they are unconditional)
     } else if (TWO) {
@@ -255,13 +273,16 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
         default: narrow_write_x<RCV_LOAD_NCHW, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, false, tid); break;
       }
     }
+    RCVS_SEG(1);
     const int ntile = tile + gridDim.x;
     // next tile's loads: in flight during the contraction and the stores below.  Unconditional (the last iteration re-requests its
     // own tile, L2 hits): behind a branch the compiler parks a vmcnt(0) in front of the contraction where the two paths meet.
     const NarrowTile nxt = narrow_decode<KIND>(a, ntile < a.total_tiles ? ntile : tile);
     prefetch(nxt);
+    RCVS_SEG(2);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    RCVS_SEG(3);
 
     // ---- contraction
     if (a.flags & RCV_F_DBG_NOMFMA) { tile = ntile; cur = nxt; continue; }      // profiling ablation
@@ -338,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
       contract(std::integral_constant<int, 0>{});
     }
 
+    RCVS_SEG(4);
     // ---- stores + statistics of this tile (statistics stay in registers).  Per block: two compares against the tile's limits, one
     // address add; everything else about a block's position is a lane constant.  The statistics kind, the residual flag and the ReLU flag select one
     // of sixteen straight-line copies of the epilogue per TILE (uniform branch): as run-time tests inside the block loop they cost a
@@ -428,9 +450,13 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
       case RCV_STATS_BWD_DEC: epilogue_r(std::integral_constant<int, RCV_STATS_BWD_DEC>{}); break;
       default: epilogue_r(std::integral_constant<int, RCV_STATS_NONE>{}); break;
     }
+    RCVS_SEG(5);
     tile = ntile;
     cur = nxt;
   }
+#ifdef RCV_STAMPS
+  RCVS_STAMP(st_loop1);
+#endif
 
   // ---- one statistics row per workgroup
   if (a.stats != RCV_STATS_NONE) {
@@ -465,6 +491,19 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
       a.part[((size_t)blockIdx.x * 2 + which) * a.Cout + co] = u;
     }
   }
+#ifdef RCV_STAMPS
+  if (a.stamps) {
+    unsigned long long st_end;
+    RCVS_STAMP(st_end);
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+      unsigned long long* o = a.stamps + ((size_t)blockIdx.x * WAVES + wave) * 12;
+      o[0] = st_loop0 - st_k0; o[1] = st_loop1 - st_loop0; o[2] = st_end - st_loop1;
+      for (int k2 = 0; k2 < 6; ++k2) o[3 + k2] = st_seg[k2];
+      o[9] = rt1 - st_rt0; o[10] = st_end - st_k0; o[11] = st_rt0;
+    }
+  }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------

@@ -84,6 +84,8 @@ if stamps is not None:
     st = stamps.view(-1, 12).cpu().double()
     st = st[st[:, 10] > 0]
     names = ["prologue", "loop", "epilogue", "wait_vm_lgkm", "barrier", "dma_issue", "taps0-5", "write_x+load_x", "taps5-9", "realtime(10ns)", "kernel_cycles"]
+    if label.startswith("convs_") or label.startswith("tconvms_"):     # narrow kernel: phases of the tile loop
+        names = ["prologue", "tile loop", "tail", "barrier A", "wait+write_x", "decode+prefetch", "barrier B", "contraction", "epilogue", "realtime(10ns)", "kernel_cycles"]
     tot = st[:, 10].mean()
     print("waves %d; mean shader cycles per wave %.0f; shader clock %.2f GHz" % (st.shape[0], tot, (st[:, 10] / (st[:, 9] * 10.0)).mean()))
     for k, nm in enumerate(names[:9]):
