@@ -66,9 +66,12 @@ __device__ __forceinline__ NarrowTile narrow_decode(const ConvArgs& a, int t) {
   return ti;
 }
 
-template <int MODE, int XMAX, int AMAX, int CK>
+// PAD: the tile touches the border of the plane (slots outside it are written as zeros).  A template parameter and a uniform branch at
+// the call, not a run-time flag in here: as a flag the compiler turns it into two more selects per element on EVERY tile (10 of the
+// 14 vector instructions of an interior slot).
+template <int MODE, int XMAX, int AMAX, int CK, bool PAD>
 __device__ __forceinline__ void narrow_write_x(const ConvArgs& a, float* xl, const float* cl, const float4 (&px)[XMAX],
-                                               const float4 (&pa)[AMAX], uint32_t okmask, bool interior, int tid) {
+                                               const float4 (&pa)[AMAX], uint32_t okmask, int tid) {
   constexpr int Q = CK / 4, STEP = 256 / Q;
   const int S = a.xpitch;
   const int q = tid % Q, lpix = tid / Q;
@@ -83,7 +86,7 @@ __device__ __forceinline__ void narrow_write_x(const ConvArgs& a, float* xl, con
   for (int u = 0; u < XMAX; ++u) {
     if (lpix < npix - u * STEP) {                // (right side uniform)
       float4 v = xform4<MODE>(px[u], pa[AMAX == XMAX ? u : 0], k);
-      if (!interior && !((okmask >> u) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding AFTER the transform
+      if (PAD && !((okmask >> u) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);      // zero padding AFTER the transform
       float* d = d0 + u * STEP * S;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -260,18 +263,26 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     RCVS_SEG(0);
+    auto write_x = [&](auto pad_c) {
+      constexpr bool PAD = decltype(pad_c)::value;
+      if (TWO) {
+        if (a.in_mode == RCV_LOAD_GRAD_ENC) narrow_write_x<RCV_LOAD_GRAD_ENC, XMAX, AMAX, CK, PAD>(a, xl, cl, px, pa, okmask, tid);
+        else narrow_write_x<RCV_LOAD_GRAD_DEC, XMAX, AMAX, CK, PAD>(a, xl, cl, px, pa, okmask, tid);
+      } else {
+        switch (a.in_mode) {
+          case RCV_LOAD_PLAIN: narrow_write_x<RCV_LOAD_PLAIN, XMAX, AMAX, CK, PAD>(a, xl, cl, px, pa, okmask, tid); break;
+          case RCV_LOAD_AFFINE: narrow_write_x<RCV_LOAD_AFFINE, XMAX, AMAX, CK, PAD>(a, xl, cl, px, pa, okmask, tid); break;
+          case RCV_LOAD_AFFINE_RELU: narrow_write_x<RCV_LOAD_AFFINE_RELU, XMAX, AMAX, CK, PAD>(a, xl, cl, px, pa, okmask, tid); break;
+          default: narrow_write_x<RCV_LOAD_NCHW, XMAX, AMAX, CK, true>(a, xl, cl, px, pa, okmask, tid); break;
+        }
+      }
+    };
     if (a.flags & RCV_F_DBG_NOSTAGE) {
       // profiling ablation: no LDS writes (the prefetch loads below are still issued: they are unconditional)
-    } else if (TWO) {
-      if (a.in_mode == RCV_LOAD_GRAD_ENC) narrow_write_x<RCV_LOAD_GRAD_ENC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, cur.interior, tid);
-      else narrow_write_x<RCV_LOAD_GRAD_DEC, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, cur.interior, tid);
+    } else if (cur.interior && !nchw) {
+      write_x(std::integral_constant<bool, false>{});
     } else {
-      switch (a.in_mode) {
-        case RCV_LOAD_PLAIN: narrow_write_x<RCV_LOAD_PLAIN, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, cur.interior, tid); break;
-        case RCV_LOAD_AFFINE: narrow_write_x<RCV_LOAD_AFFINE, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, cur.interior, tid); break;
-        case RCV_LOAD_AFFINE_RELU: narrow_write_x<RCV_LOAD_AFFINE_RELU, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, cur.interior, tid); break;
-        default: narrow_write_x<RCV_LOAD_NCHW, XMAX, AMAX, CK>(a, xl, cl, px, pa, okmask, false, tid); break;
-      }
+      write_x(std::integral_constant<bool, true>{});
     }
     RCVS_SEG(1);
     const int ntile = tile + gridDim.x;
@@ -311,6 +322,9 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
     for (int m = 0; m < WM; ++m)
 #pragma unroll
       for (int b = 0; b < WN; ++b) acc[m][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // wave priority: the MFMA phase yields to the staging / epilogue phases of the other wave on the SIMD (whose vector instructions
+    // otherwise queue behind the back-to-back MFMAs): +2...7 % on the layers with short contractions, neutral elsewhere
+    __builtin_amdgcn_s_setprio(0);
     // SC: LDS pitch of a staged pixel as a compile-time constant (dilation 1): the tap's column offset and the k-step are then immediate
     // offsets of the LDS reads and a pixel block needs one address register per tap ROW instead of one per tap (45 -> 15 registers for a
     // 3x3 filter and five blocks); SC = 0: run-time pitch and dilation
@@ -359,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
       contract(std::integral_constant<int, 0>{});
     }
 
+    __builtin_amdgcn_s_setprio(3);
     RCVS_SEG(4);
     // ---- stores + statistics of this tile (statistics stay in registers).  Per block: two compares against the tile's limits, one
     // address add; everything else about a block's position is a lane constant.  The statistics kind, the residual flag and the ReLU flag select one
