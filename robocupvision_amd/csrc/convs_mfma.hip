@@ -163,20 +163,22 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
   uint32_t okmask = 0;
   auto prefetch = [&](const NarrowTile& ti) {
     if (nchw) {
+      // quad q of a pixel = planes 4q .. 4q+3 of the image (<= 4 channels: one quad; 8 channels, LabelProp's input: two).  Branch-free
+      // like the NHWC path: clamped coordinates and plane indices, validity in okmask / the channel masks.
       okmask = 0;
+      const uint32_t plane = (uint32_t)(a.H * a.W);
+      const int c0 = 4 * q;
+      uint32_t cpl[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cpl[j] = (uint32_t)(ti.n * a.Cin + (c0 + j < a.Cin ? c0 + j : a.Cin - 1)) * plane;
 #pragma unroll
       for (int u = 0; u < XMAX; ++u) {
-        px[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int gy = ti.oy0 + (int)(sxy[u] >> 16), gx = ti.ox0 + (int)(sxy[u] & 0xffffu);
-        if (Q == 1 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) {
-          okmask |= 1u << u;
-          const size_t plane = (size_t)a.H * a.W;
-          const size_t base = (size_t)ti.n * a.Cin * plane + (size_t)gy * a.W + gx;
-          if (0 < a.Cin) px[u].x = a.in[base];
-          if (1 < a.Cin) px[u].y = a.in[base + plane];
-          if (2 < a.Cin) px[u].z = a.in[base + 2 * plane];
-          if (3 < a.Cin) px[u].w = a.in[base + 3 * plane];
-        }
+        const bool inside = Q <= 2 && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+        okmask |= (inside ? 1u : 0u) << u;
+        const uint32_t pos = inside ? (uint32_t)(gy * a.W + gx) : 0u;
+        const float v0 = a.in[cpl[0] + pos], v1 = a.in[cpl[1] + pos], v2 = a.in[cpl[2] + pos], v3 = a.in[cpl[3] + pos];
+        px[u] = make_float4(v0, c0 + 1 < a.Cin ? v1 : 0.f, c0 + 2 < a.Cin ? v2 : 0.f, c0 + 3 < a.Cin ? v3 : 0.f);
       }
     } else {
       // Branch-free loads (behind divergent branches the compiler waits for each load on the spot and nothing stays in flight across

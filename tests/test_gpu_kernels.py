@@ -72,6 +72,36 @@ def test_conv_kernels_vs_fp64(N, H, W, Cin, Cout, s, mode_name):
         assert err <= (2e-6 if wino else 3e-6), (label, err)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,s,d", [(2, 48, 64, 3, 8, 1, 1), (2, 120, 160, 8, 8, 1, 1), (3, 37, 53, 8, 8, 1, 1), (2, 48, 64, 8, 16, 2, 1),
+                                               (2, 40, 56, 8, 8, 1, 2), (1, 33, 47, 3, 16, 2, 1), (2, 24, 40, 6, 8, 1, 1)])
+def test_conv_nchw_image_input_vs_fp64(N, H, W, Cin, Cout, s, d):
+    """RCV_LOAD_NCHW: the graph input in the reference's own layout (ROBO-UNet's 3-channel image, LabelProp's 8-channel frame pair) read by the
+    first conv without an NHWC copy -- one channel quad per pixel up to 4 channels, two for 5..8 (narrow-layer kernel)."""
+    from robocupvision_amd import _lib as L
+    h = L.handle(0)
+    gen = torch.Generator().manual_seed(77 + H * W + Cin)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    x, w, b = _rand(gen, N, Cin, H, W), _rand(gen, Cout, Cin, 3, 3, scale=0.2), _rand(gen, Cout)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=d, dilation=d)).permute(0, 2, 3, 1)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    rp, cp = (Cin + 3) // 4 * 4, (Cout + 15) // 16 * 16
+    wp = torch.zeros(9 * rp * cp, device=DEV)
+    job = L.RcvPackJob()
+    job.src, job.dst, job.D0, job.D1 = wd.data_ptr(), wp.data_ptr(), Cout, Cin
+    job.rows_from_d1, job.flip, job.rows_pad, job.cols_pad, job.merged = 1, 0, rp, cp, 0
+    table = torch.frombuffer(bytearray(bytes((L.RcvPackJob * 1)(job))), dtype=torch.uint8).to(DEV)
+    out = torch.full((N, Ho, Wo, Cout), float("nan"), device=DEV)
+    pack = L.make_op(L.OP_PACK, 0, count=1, aux0=9 * rp * cp, p_in=table.data_ptr())
+    conv = L.make_op(L.OP_CONV, L.F_BIAS | L.F_RELU, n=N, h=H, w=W, cin=Cin, cout=Cout, ho=Ho, wo=Wo, stride=s, dil=d, inmode=L.LOAD_NCHW,
+                     p_in=xd.data_ptr(), p_w=wp.data_ptr(), p_bias=bd.data_ptr(), p_out=out.data_ptr())
+    lst = L.OpList([pack, conv])
+    label = lst.labels(h)[1]
+    lst.run(h, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 3e-6, (label, err)
+
+
 WGRAD_SHAPES = [(4, 15, 20, 64, 64, 1), (4, 30, 40, 32, 64, 2), (4, 15, 20, 64, 128, 1), (4, 15, 20, 128, 128, 1), (4, 30, 40, 32, 32, 1),
                 (4, 60, 80, 16, 16, 1), (4, 120, 160, 8, 16, 2), (2, 15, 20, 64, 64, 1), (4, 16, 20, 64, 64, 1), (4, 15, 24, 64, 64, 1),
                 (3, 5, 7, 64, 64, 1), (4, 10, 14, 128, 64, 1), (64, 15, 20, 64, 64, 1), (1, 30, 40, 64, 64, 1), (4, 7, 10, 128, 128, 1),
