@@ -10,7 +10,10 @@
 //     twice that for the two-tensor gradient loads) before the MFMA phase of the current tile and written to
 //     LDS after it, so every CU keeps >= 64 KiB of HBM reads in flight while it computes and stores;
 //   * BatchNorm partial sums are accumulated in registers ACROSS tiles and reduced once per workgroup
-//     (one partial row per workgroup instead of one per tile): fixed order, no atomics.
+//     (one partial row per workgroup instead of one per tile): fixed order, no atomics;
+//   * per-tile vector-ALU work is kept minimal (next to MFMAs a wave's other vector instructions advance at about one per MFMA):
+//     staging slots and output blocks carry tile-relative byte offsets and packed 16-bit tile coordinates as lane constants, a tile
+//     adds scalar bases, interior tiles skip all bounds work, the epilogue variant (statistics x residual x ReLU) is chosen per tile.
 // A workgroup is 4 waves side by side along the pixels; every wave covers all (virtual) output channels
 // (WM blocks of 16) for its WN blocks of 16 pixels.  Kinds: KIND_GATHER (stride 1|2, dilation 1|2) and
 // KIND_TMERGED (transposed conv, merged-parity layout, see conv_mfma.hip).
