@@ -45,8 +45,29 @@ __global__ __launch_bounds__(384) void wgrad_first_kernel(const WgradArgs a, int
 #pragma unroll
   for (int c = 0; c < 4; ++c) bs[c] = 0.f;
 
+  // Staging slots of a thread (the same for every tile): image element e = tid + u * NT of the [ci][row][col] tile -> offset relative to
+  // the tile's first halo pixel and packed (row, column); dz pixel (tid >> 1) + u * NT / 2, channel quad tid & 1.
+  constexpr int UNR = 3;                                  // 3 * 192 = 576 >= 512 dz pixels
+  constexpr int PER_PLANE = IH * IW, NU = (3 * PER_PLANE + NT - 1) / NT;
+  const int total = a.CA * PER_PLANE;
+  const int q = tid & 1;
+  const float* p_aux = p_two ? a.p_aux : a.p;             // (one-tensor modes: the second load repeats the first, L1 hit)
+  int irel[NU];
+  uint32_t iyx[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int e = tid + u * NT;
+    const int ec = e < total ? e : 0;
+    const int c = ec / PER_PLANE, r = ec - c * PER_PLANE;
+    const int iy = r / IW, ix = r - iy * IW;
+    irel[u] = c * (int)plane + iy * a.W + ix;
+    iyx[u] = (uint32_t)(e < total ? iy : 0x7fff) << 16 | (uint32_t)ix;      // slots past the tile: row 32767, never inside the plane
+  }
+
   // (A register-prefetch pipeline -- loads of tile i+1 issued branch-free before the arithmetic of tile i -- was measured: 0.246 vs
-  // 0.251 ms at 32x480x640 and slower on small planes; what bounds the kernel is the number of bytes in flight per CU.)
+  // 0.251 ms at 32x480x640 and slower on small planes; what bounds the kernel is the number of bytes in flight per CU.  Round 2: ALL
+  // loads of a tile -- the dz quads and the image values -- are requested in one branch-free batch: staged one after the other, and the
+  // image in two passes, a tile cost three HBM round trips.)
   for (int tile = split; tile < total_tiles; tile += gridDim.x) {
     int t = tile;
     const int tx_i = t % tiles_x; t /= tiles_x;
@@ -54,25 +75,28 @@ __global__ __launch_bounds__(384) void wgrad_first_kernel(const WgradArgs a, int
     const int n = t / tiles_y;
     const int y0 = ty_i * TY, x0 = tx_i * TX;
     __syncthreads();                                      // the previous tile is consumed
-    {   // ---- dz tile: thread -> quad (tid & 1) of pixels tid/2 + 192*u; 6 independent 16-byte loads in flight
-      const int q = tid & 1;
-      constexpr int UNR = 3;                              // 3 * 192 = 576 >= 512 pixels
-      float4 x[UNR], ax[UNR];
-      bool ok[UNR];
+    float4 x[UNR], ax[UNR];
+    bool ok[UNR];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int pix = (tid >> 1) + u * (NT / 2);
-        const int iy = pix >> 6, ix = pix & 63;
-        const int gy = y0 + iy, gx = x0 + ix;
-        ok[u] = pix < TY * TX && gy < a.Hp && gx < a.Wp;
-        x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ax[u] = x[u];
-        if (ok[u]) {
-          const size_t off = ((size_t)(n * a.Hp + gy) * a.Wp + gx) * a.CB + 4 * q;
-          x[u] = wld4(a.p + off);
-          if (p_two) ax[u] = wld4(a.p_aux + off);
-        }
-      }
+    for (int u = 0; u < UNR; ++u) {
+      const int pix = (tid >> 1) + u * (NT / 2);
+      const int iy = pix >> 6, ix = pix & 63;
+      const int gy = y0 + iy, gx = x0 + ix;
+      ok[u] = pix < TY * TX && gy < a.Hp && gx < a.Wp;
+      const uint32_t off = ok[u] ? (uint32_t)(((n * a.Hp + gy) * a.Wp + gx) * a.CB + 4 * q) : 0u;      // (host: < 2^31 elements)
+      x[u] = wld4(a.p + off);
+      ax[u] = wld4(p_aux + off);
+    }
+    float vimg[NU];
+    bool iok[NU];
+    const int ibase = n * a.CA * (int)plane + (y0 - DIL) * a.W + (x0 - DIL);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int gy = y0 - DIL + (int)(iyx[u] >> 16), gx = x0 - DIL + (int)(iyx[u] & 0xffffu);
+      iok[u] = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      vimg[u] = a.g[iok[u] ? (uint32_t)(ibase + irel[u]) : 0u];
+    }
+    {   // ---- dz tile: BN/ReLU backward while it goes to LDS
       float4 k[5];                                        // from LDS, behind the tile loads: not live while those are in flight
 #pragma unroll
       for (int j = 0; j < 5; ++j) k[j] = kc[q * 5 + j];
@@ -80,32 +104,17 @@ __global__ __launch_bounds__(384) void wgrad_first_kernel(const WgradArgs a, int
       for (int u = 0; u < UNR; ++u) {
         const int pix = (tid >> 1) + u * (NT / 2);
         if (pix < TY * TX) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (ok[u]) v = wxform_rt(a.p_mode, x[u], ax[u], k);
+          float4 v = wxform_rt(a.p_mode, x[u], ax[u], k);
+          if (!ok[u]) v = make_float4(0.f, 0.f, 0.f, 0.f);
           dzs[pix * 2 + q] = v;
         }
       }
     }
-    {   // ---- image tile: CA planes of IH x IW with zero padding, coalesced row reads, 4 loads in flight
-      const int per_plane = IH * IW, total = a.CA * per_plane;
-      for (int e0 = tid; e0 < total; e0 += 4 * NT) {
-        float v[4];
-        int dst[4];
+    // ---- image tile: CA planes of IH x IW with zero padding
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u * NT;
-          v[u] = 0.f; dst[u] = -1;
-          if (e < total) {
-            const int c = e / per_plane, r = e - c * per_plane;
-            const int iy = r / IW, ix = r - iy * IW;
-            const int gy = y0 - DIL + iy, gx = x0 - DIL + ix;
-            dst[u] = e;
-            if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W) v[u] = a.g[((size_t)n * a.CA + c) * plane + (size_t)gy * a.W + gx];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) if (dst[u] >= 0) xs[dst[u]] = v[u];
-      }
+    for (int u = 0; u < NU; ++u) {
+      const int e = tid + u * NT;
+      if (e < total) xs[e] = iok[u] ? vimg[u] : 0.f;
     }
     __syncthreads();
     if (ci < a.CA) {
