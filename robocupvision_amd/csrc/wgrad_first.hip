@@ -65,7 +65,8 @@ __global__ __launch_bounds__(384) void wgrad_first_kernel(const WgradArgs a, int
   }
 
   // (A register-prefetch pipeline -- loads of tile i+1 issued branch-free before the arithmetic of tile i -- was measured: 0.246 vs
-  // 0.251 ms at 32x480x640 and slower on small planes; what bounds the kernel is the number of bytes in flight per CU.  Round 2: ALL
+  // 0.251 ms at 32x480x640 and slower on small planes -- and again on top of the one-batch staging below: 0.239 vs 0.179 ms; what bounds
+  // the kernel is the number of bytes in flight per CU.  Round 2: ALL
   // loads of a tile -- the dz quads and the image values -- are requested in one branch-free batch: staged one after the other, and the
   // image in two passes, a tile cost three HBM round trips.)
   for (int tile = split; tile < total_tiles; tile += gridDim.x) {
