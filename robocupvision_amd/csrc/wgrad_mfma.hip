@@ -376,40 +376,53 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
 }
 
 // dW[cb][ca][tap] = sum_split part[split][tap][cb][ca];  db[cb] = sum_split part_bias[split][cb]
-// 64 consecutive partial-layout elements x 4 split groups per workgroup (block `blk` of this layer); every thread keeps 4 loads in
-// flight; the order of additions is a fixed function of (nsplit) => bitwise reproducible.
+// 64 consecutive partial-layout elements per workgroup (block `blk` of this layer), 16 split groups of 16 threads: a thread sums one
+// 16-byte piece over the splits sidx = group, group + 16, ... with four 16-byte loads in flight -- up to 64 splits are ONE round trip.
+// (A thread per element with four split groups and 4-byte loads: 35 us per batched launch of the headline step against 31; 256-element
+// blocks with 1 KB runs per split and eight loads in flight: 37 -- a quarter of the workgroups.)  The order of additions is a fixed
+// function of (nsplit) => bitwise reproducible.
 __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ part, const float* __restrict__ part_bias, float* __restrict__ dw,
                                                    float* __restrict__ db, int nsplit, int CB, int CA, int CBP, int CAP, int blk,
-                                                   double (&sh)[4][64]) {
-  const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int totalP = 9 * CBP * CAP;
-  const int e = blk * 64 + el;
-  const size_t stride = (size_t)totalP;
-  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;     // double: bias / BN-adjacent filters are cancellation-heavy sums
+                                                   double (&sh)[16][64]) {
+  const int el4 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int totalP = 9 * CBP * CAP;                     // a multiple of 64: a block lies entirely in the filter part or in the bias row
+  const int e = blk * 64 + 4 * el4;
+  double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};     // double: bias / BN-adjacent filters are cancellation-heavy sums
   const float* src = nullptr;
   size_t st = 0;
-  if (e < totalP) { src = part + e; st = stride; }
+  if (e < totalP) { src = part + e; st = (size_t)totalP; }
   else if (part_bias && e < totalP + CBP) { src = part_bias + (e - totalP); st = (size_t)CBP; }
   if (src) {
     int sidx = grp;
-    for (; sidx + 12 < nsplit; sidx += 16) {
-      a0 += (double)src[(size_t)sidx * st]; a1 += (double)src[(size_t)(sidx + 4) * st];
-      a2 += (double)src[(size_t)(sidx + 8) * st]; a3 += (double)src[(size_t)(sidx + 12) * st];
+    for (; sidx + 48 < nsplit; sidx += 64) {
+      const float4 v0 = wld4(src + (size_t)sidx * st), v1 = wld4(src + (size_t)(sidx + 16) * st);
+      const float4 v2 = wld4(src + (size_t)(sidx + 32) * st), v3 = wld4(src + (size_t)(sidx + 48) * st);
+      a0[0] += (double)v0.x + (double)v2.x; a0[1] += (double)v0.y + (double)v2.y; a0[2] += (double)v0.z + (double)v2.z; a0[3] += (double)v0.w + (double)v2.w;
+      a1[0] += (double)v1.x + (double)v3.x; a1[1] += (double)v1.y + (double)v3.y; a1[2] += (double)v1.z + (double)v3.z; a1[3] += (double)v1.w + (double)v3.w;
     }
-    for (; sidx < nsplit; sidx += 4) a0 += (double)src[(size_t)sidx * st];
+    for (; sidx < nsplit; sidx += 16) {
+      const float4 v = wld4(src + (size_t)sidx * st);
+      a0[0] += (double)v.x; a0[1] += (double)v.y; a0[2] += (double)v.z; a0[3] += (double)v.w;
+    }
   }
-  sh[grp][el] = (a0 + a1) + (a2 + a3);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sh[grp][4 * el4 + j] = a0[j] + a1[j];
   __syncthreads();
-  if (grp == 0 && src) {
-    const float u = (float)((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]));
-    if (e < totalP) {
-      const int ca = e % CAP;
-      const int cb = (e / CAP) % CBP;
-      const int t = e / (CAP * CBP);
-      if (ca < CA && cb < CB) dw[((size_t)cb * CA + ca) * 9 + t] = u;
-    } else {
-      const int cb = e - totalP;
-      if (db && cb < CB) db[cb] = u;
+  const int el = threadIdx.x;
+  if (el < 64) {
+    const int e1 = blk * 64 + el;
+    double u = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; g += 4) u += (sh[g][el] + sh[g + 1][el]) + (sh[g + 2][el] + sh[g + 3][el]);
+    const float uf = (float)u;
+    if (e1 < totalP) {
+      const int ca = e1 % CAP;
+      const int cb = (e1 / CAP) % CBP;
+      const int t = e1 / (CAP * CBP);
+      if (ca < CA && cb < CB) dw[((size_t)cb * CA + ca) * 9 + t] = uf;
+    } else if (part_bias && e1 < totalP + CBP) {
+      const int cb = e1 - totalP;
+      if (db && cb < CB) db[cb] = uf;
     }
   }
 }
@@ -417,13 +430,13 @@ __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ par
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_bias,
                                                            float* __restrict__ dw, float* __restrict__ db, int nsplit, int CB, int CA,
                                                            int CBP, int CAP) {
-  __shared__ double sh[4][64];
+  __shared__ double sh[16][64];
   wgrad_reduce_block(part, part_bias, dw, db, nsplit, CB, CA, CBP, CAP, blockIdx.x, sh);
 }
 
 // several layers in one launch (RCV_OP_WGRAD_REDUCE_BATCH): the workgroup finds its job in the (<= 64 rows) table
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const rcv_reduce_job* __restrict__ jobs, int njobs) {
-  __shared__ double sh[4][64];
+  __shared__ double sh[16][64];
   int j = 0;
   while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].first_block) ++j;
   const rcv_reduce_job jb = jobs[j];
