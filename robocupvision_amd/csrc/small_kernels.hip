@@ -866,6 +866,77 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dp, const float* __res
   }
 }
 
+// The same, with lanes mapped to the INPUT rows: a thread owns one 16-byte piece (pixel column, channel quad) of the two input rows of
+// an output row, so that every load and store instruction of a wave covers 1 KB of consecutive memory (in the kernel above a thread owns
+// an output pixel and each of its four window loads touches half of every 128-byte line: 3.4 TB/s on the U-Net configuration).  The two
+// columns of a window sit C/4 lanes apart: one cross-lane exchange of (row maximum, row index) decides the window.  First maximum in the
+// window order (0,0), (0,1), (1,0), (1,1) wins ties, as in the kernel above and in aten::max_pool2d_with_indices.
+// Needs C/4 a power of two < 64 and W * C/4 a multiple of 64 (a window's two lanes then lie in one wave); blockDim.x a multiple of C/4.
+template <int MODE>
+__global__ void pool_bwd_rows_kernel(const float* __restrict__ dp, const float* __restrict__ r, const float* __restrict__ cst,
+                                     const float* __restrict__ resid, float* __restrict__ dy, float* __restrict__ part, int N, int H,
+                                     int W, int C, int stats) {
+  extern __shared__ float4 sh4[];
+  const int C4 = C / 4, Ho = H / 2, Wo = W / 2, RW = W * C4;       // RW: 16-byte pieces of an input row
+  const size_t total = (size_t)N * Ho * RW;
+  const int q = threadIdx.x % C4;
+  float4 s = make_float4(1.f, 1.f, 1.f, 1.f), h = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE != RCV_LOAD_PLAIN) { s = sld4(cst + 4 * q); h = sld4(cst + C + 4 * q); if (stats != RCV_STATS_NONE) mu = sld4(cst + 2 * C + 4 * q); }
+  float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+  const size_t nloop = (total + (size_t)gridDim.x * blockDim.x - 1) / ((size_t)gridDim.x * blockDim.x);      // uniform trip count: the exchange below needs every lane
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t it = 0; it < nloop; ++it, e += (size_t)gridDim.x * blockDim.x) {
+    const bool live = e < total;
+    const size_t ec = live ? e : total - 1;
+    const size_t orow = ec / RW;                          // n * Ho + oy
+    const int i = (int)(ec - orow * RW);                  // piece of the row: column i / C4, quad i % C4 (== q)
+    const int col = i / C4, jx = col & 1;
+    const size_t in0 = (orow * 2) * (size_t)RW * 4 + (size_t)i * 4;       // element offset of this piece in input row 2 oy
+    const size_t in1 = in0 + (size_t)RW * 4;
+    const float4 r0 = sld4(r + in0), r1 = sld4(r + in1);
+    const float4 g = sld4(dp + (orow * Wo + (col >> 1)) * C + 4 * q);
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0;
+    if (resid) { q0 = sld4(resid + in0); q1 = sld4(resid + in1); }
+    const float v0[4] = {fmaf(r0.x, s.x, h.x), fmaf(r0.y, s.y, h.y), fmaf(r0.z, s.z, h.z), fmaf(r0.w, s.w, h.w)};
+    const float v1[4] = {fmaf(r1.x, s.x, h.x), fmaf(r1.y, s.y, h.y), fmaf(r1.z, s.z, h.z), fmaf(r1.w, s.w, h.w)};
+    const float gg[4] = {g.x, g.y, g.z, g.w};
+    float d0[4], d1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // this column: rows 0 / 1 are window positions jx / 2 + jx; the other column's pair arrives from C4 lanes away
+      const bool low = v1[c] > v0[c];
+      const float best = low ? v1[c] : v0[c];
+      const int idx = (low ? 2 : 0) + jx;
+      const float pbest = __shfl_xor(best, C4);
+      const int pidx = __shfl_xor(idx, C4);
+      const bool mine = best > pbest || (best == pbest && idx < pidx);
+      d0[c] = (mine && !low) ? gg[c] : 0.f;
+      d1[c] = (mine && low) ? gg[c] : 0.f;
+    }
+    if (live) {
+      const float4 o0 = make_float4(d0[0] + q0.x, d0[1] + q0.y, d0[2] + q0.z, d0[3] + q0.w);
+      const float4 o1 = make_float4(d1[0] + q1.x, d1[1] + q1.y, d1[2] + q1.z, d1[3] + q1.w);
+      sst4(dy + in0, o0);
+      sst4(dy + in1, o1);
+      a1.x += o0.x + o1.x; a1.y += o0.y + o1.y; a1.z += o0.z + o1.z; a1.w += o0.w + o1.w;
+      a2.x = fmaf(o0.x, r0.x - mu.x, a2.x); a2.y = fmaf(o0.y, r0.y - mu.y, a2.y); a2.z = fmaf(o0.z, r0.z - mu.z, a2.z); a2.w = fmaf(o0.w, r0.w - mu.w, a2.w);
+      a2.x = fmaf(o1.x, r1.x - mu.x, a2.x); a2.y = fmaf(o1.y, r1.y - mu.y, a2.y); a2.z = fmaf(o1.z, r1.z - mu.z, a2.z); a2.w = fmaf(o1.w, r1.w - mu.w, a2.w);
+    }
+  }
+  if (stats != RCV_STATS_NONE) {
+    sh4[threadIdx.x] = a1;
+    sh4[blockDim.x + threadIdx.x] = a2;
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * C4) {
+      const int which = threadIdx.x / C4, qq = threadIdx.x % C4;
+      float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = qq; k < (int)blockDim.x; k += C4) { const float4 v = sh4[which * blockDim.x + k]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
+      sst4(part + ((size_t)blockIdx.x * 2 + which) * C + 4 * qq, u);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Fused optimizer step over one flat fp32 buffer: g = grad*grad_scale + decay*sign(p) (the
 // gradient of decay*sum|p|, train.py:23-27,53-55) followed by torch.optim.Adam's update
@@ -1300,7 +1371,13 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       RCV_CHECK_ARG(stats == RCV_STATS_NONE || (op->p[RCV_P_PART] && op->i[RCV_I_NPART] == g), "maxpool backward: workspace rows mismatch");
       const float* resid = (op->flags & RCV_F_RESID) ? (const float*)op->p[RCV_P_RESID] : nullptr;
       const size_t lds = 2 * 256 * sizeof(float4);
-      if (op->i[RCV_I_INMODE] == RCV_LOAD_PLAIN)
+      const int C4 = Cout / 4;
+      const bool rows = (C4 & (C4 - 1)) == 0 && C4 < 64 && ((long long)W * C4) % 64 == 0 && !RCV_ENV("RCV_NO_POOL_ROWS");      // see pool_bwd_rows_kernel
+      if (rows) {
+        if (op->i[RCV_I_INMODE] != RCV_LOAD_PLAIN) RCV_CHECK_ARG(op->p[RCV_P_IN_C], "maxpool backward: constants missing");
+        auto kern = op->i[RCV_I_INMODE] == RCV_LOAD_PLAIN ? pool_bwd_rows_kernel<RCV_LOAD_PLAIN> : pool_bwd_rows_kernel<RCV_LOAD_AFFINE>;
+        hipLaunchKernelGGL(kern, dim3(g), dim3(256), lds, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_EPI_AUX], (const float*)op->p[RCV_P_IN_C], resid, (float*)op->p[RCV_P_OUT], (float*)op->p[RCV_P_PART], N, H, W, Cout, stats);
+      } else if (op->i[RCV_I_INMODE] == RCV_LOAD_PLAIN)
         hipLaunchKernelGGL(pool_bwd_kernel<RCV_LOAD_PLAIN>, dim3(g), dim3(256), lds, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_EPI_AUX], (const float*)op->p[RCV_P_IN_C], resid, (float*)op->p[RCV_P_OUT], (float*)op->p[RCV_P_PART], N, H, W, Cout, stats);
       else {
         RCV_CHECK_ARG(op->p[RCV_P_IN_C], "maxpool backward: constants missing");

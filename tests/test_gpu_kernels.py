@@ -194,3 +194,32 @@ def test_transposed_conv_kernels_vs_fp64(N, H, W, Cin, Cout, mode_name):
     torch.cuda.synchronize()
     err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
     assert err <= 3e-6, (lst.labels(h)[1], err)
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 8, 64, 8), (2, 6, 32, 16), (1, 4, 16, 32), (3, 10, 128, 8), (2, 6, 24, 8), (1, 4, 8, 64), (2, 4, 6, 16)])
+@pytest.mark.parametrize("affine", [False, True])
+def test_maxpool_backward_first_maximum_exact(N, H, W, C, affine):
+    """RCV_OP_POOL_BWD: the pooled gradient goes to the FIRST maximum of each 2x2 window (window order (0,0), (0,1), (1,0), (1,1), as
+    aten::max_pool2d_with_indices), bit for bit, on inputs full of ties -- through the row-mapped kernel (C/4 a power of two, W*C/4 a
+    multiple of 64) and through the pixel-mapped one (the other shapes); with the producer's BatchNorm folded into the comparison
+    (positive and negative scales) and a residual added to the result."""
+    from robocupvision_amd import _lib as L
+    h = L.handle(0)
+    gen = torch.Generator().manual_seed(5 + H * W + C)
+    x = torch.randint(-3, 4, (N, H, W, C), generator=gen).float()          # few distinct values: most windows hold ties
+    g = _rand(gen, N, H // 2, W // 2, C)
+    resid = _rand(gen, N, H, W, C)
+    c = torch.zeros(5, C)
+    c[0] = torch.where(torch.arange(C) % 3 == 0, -0.5, 2.0) if affine else 1.0
+    c[1] = _rand(gen, C) if affine else 0.0
+    xv = (x * c[0] + c[1]).permute(0, 3, 1, 2).double().requires_grad_(True)
+    y = F.max_pool2d(xv, 2, 2)
+    y.backward(g.permute(0, 3, 1, 2).double())
+    ref = (xv.grad.permute(0, 2, 3, 1) + resid.double()).float()
+    xd, gd, rd, cd = x.to(DEV), g.to(DEV), resid.to(DEV), c.to(DEV)
+    out = torch.full((N, H, W, C), float("nan"), device=DEV)
+    op = L.make_op(L.OP_POOL_BWD, L.F_RESID, n=N, h=H, w=W, cout=C, inmode=L.LOAD_AFFINE if affine else L.LOAD_PLAIN, stats=L.STATS_NONE,
+                   p_in=gd.data_ptr(), p_epi_aux=xd.data_ptr(), p_in_c=cd.data_ptr(), p_resid=rd.data_ptr(), p_out=out.data_ptr())
+    L.OpList([op]).run(h, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), ref)
