@@ -99,7 +99,7 @@ enum {
   RCV_LOAD_AFFINE   = 1,   /* v = x*c0[ch] + c1[ch]                (BatchNorm apply of producer) */
   RCV_LOAD_GRAD_ENC = 2,   /* v = aux>0 ? c0*x + c1 + c2*aux : 0   (BN-bwd then ReLU-bwd)        */
   RCV_LOAD_GRAD_DEC = 3,   /* v = c0*(aux*c3+c4>0 ? x : 0) + c1 + c2*aux   (ReLU-bwd then BN-bwd)*/
-  RCV_LOAD_NCHW     = 4,   /* v = x, tensor is NCHW (network input image): <= 4 channels on every conv kernel, <= 8 where Cout <= 32 */
+  RCV_LOAD_NCHW     = 4,   /* v = x, tensor is NCHW (network input image, <= 4 channels)           */
   RCV_LOAD_AFFINE_RELU = 5 /* v = max(x*c0+c1, 0)               (conv->BN->ReLU producer)        */
 };
 

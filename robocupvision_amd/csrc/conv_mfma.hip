@@ -880,8 +880,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   RCV_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv: empty shape N=%d H=%d W=%d Cin=%d Cout=%d", N, H, W, Cin, Cout);
   RCV_CHECK_ARG(Cout % 4 == 0, "conv: Cout=%d must be a multiple of 4", Cout);
   const int mode = op->i[RCV_I_INMODE];
-  // NCHW input: <= 4 channels on every kernel, 5..8 channels on the narrow-layer kernel only (LabelProp's 8-channel frame pair)
-  if (mode == RCV_LOAD_NCHW) RCV_CHECK_ARG(Cin <= 8, "conv: NCHW input supports Cin<=8 (got %d)", Cin);
+  if (mode == RCV_LOAD_NCHW) RCV_CHECK_ARG(Cin <= 4, "conv: NCHW input supports Cin<=4 (got %d)", Cin);
   else RCV_CHECK_ARG(Cin % 4 == 0, "conv: Cin=%d must be a multiple of 4 for NHWC operands", Cin);
   if (transposed) {
     RCV_CHECK_ARG(Ho == 2 * H && Wo == 2 * W, "tconv: output must be 2x input (%dx%d -> %dx%d)", H, W, Ho, Wo);
@@ -901,7 +900,6 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   RCV_CHECK_ARG(transposed || op->i[RCV_I_AUX0] != 2, "conv: a filter packed in the Winograd layout needs stride 1 / dilation 1");
   if (conv_first_supported(op, pl->kind)) return conv_first_plan(h, op, pl);
   if (convs_supported(h, op, pl->kind, CinP, pl->kind == KIND_TMERGED ? 4 * Cout : Cout)) return convs_make_plan(h, op, pl->kind, pl);
-  RCV_CHECK_ARG(mode != RCV_LOAD_NCHW || Cin <= 4, "conv: NCHW input with %d channels needs the narrow-layer kernel (<= 32 output channels)", Cin);
   pl->CK = (CinP % 8 == 0) ? 8 : 4;
   const int Q = pl->CK / 4;
   pl->CoutV = pl->kind == KIND_TMERGED ? 4 * Cout : Cout;

@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int npix = a.IH * a.IW;
-  const bool nchw = a.in_mode == RCV_LOAD_NCHW;
+  // (an NCHW image has at most 4 channels here and is never a gradient operand: the other instantiations do not carry that path --
+  // compiled into all of them it cost every one-tensor variant ~6 registers and 8 spilled SGPRs: 1-2 % of the whole step)
+  const bool nchw = CK == 4 && !TWO && KIND == KIND_GATHER && a.in_mode == RCV_LOAD_NCHW;
   const bool need_e = a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC;
 
   // ---- once per workgroup: load constants, epilogue constants and the whole filter
@@ -166,8 +168,7 @@ __global__ __launch_bounds__(256, 2) void convs_mfma_kernel(const ConvArgs a) {
   uint32_t okmask = 0;
   auto prefetch = [&](const NarrowTile& ti) {
     if (nchw) {
-      // quad q of a pixel = planes 4q .. 4q+3 of the image (<= 4 channels: one quad; 8 channels, LabelProp's input: two).  Branch-free
-      // like the NHWC path: clamped coordinates and plane indices, validity in okmask / the channel masks.
+      // quad q of a pixel = planes 4q .. 4q+3 of the image (one quad: <= 4 channels).  Branch-free like the NHWC path: clamped coordinates and plane indices, validity in okmask / the channel masks.
       okmask = 0;
       const uint32_t plane = (uint32_t)(a.H * a.W);
       const int c0 = 4 * q;

@@ -72,11 +72,11 @@ def test_conv_kernels_vs_fp64(N, H, W, Cin, Cout, s, mode_name):
         assert err <= (2e-6 if wino else 3e-6), (label, err)
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout,s,d", [(2, 48, 64, 3, 8, 1, 1), (2, 120, 160, 8, 8, 1, 1), (3, 37, 53, 8, 8, 1, 1), (2, 48, 64, 8, 16, 2, 1),
-                                               (2, 40, 56, 8, 8, 1, 2), (1, 33, 47, 3, 16, 2, 1), (2, 24, 40, 6, 8, 1, 1)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,s,d", [(2, 48, 64, 3, 8, 1, 1), (2, 120, 160, 3, 16, 1, 1), (3, 37, 53, 4, 16, 1, 1), (2, 48, 64, 3, 16, 2, 1),
+                                               (2, 40, 56, 3, 8, 1, 2), (1, 33, 47, 3, 16, 2, 1), (2, 24, 40, 2, 32, 1, 2)])
 def test_conv_nchw_image_input_vs_fp64(N, H, W, Cin, Cout, s, d):
-    """RCV_LOAD_NCHW: the graph input in the reference's own layout (ROBO-UNet's 3-channel image, LabelProp's 8-channel frame pair) read by the
-    first conv without an NHWC copy -- one channel quad per pixel up to 4 channels, two for 5..8 (narrow-layer kernel)."""
+    """RCV_LOAD_NCHW: the graph input in the reference's own layout (the 3-channel image) read by the first conv without an NHWC copy --
+    on the first-layer kernel (8 output channels, stride 1) and on the narrow-layer kernel (the other shapes)."""
     from robocupvision_amd import _lib as L
     h = L.handle(0)
     gen = torch.Generator().manual_seed(77 + H * W + Cin)
