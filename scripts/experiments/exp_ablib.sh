@@ -5,7 +5,7 @@ O=gpurun_out/ablib.log
 : > $O
 for r in 1 2; do
 for L in librcv_A.so librcv.so; do
-  for w in labelprop_160x120_b64 robo_unet_640x480_bs32 unet_640x480_bs32 robo_unet_160x120_bs64; do
+  for w in ${WORKLOADS:-labelprop_160x120_b64 robo_unet_640x480_bs32 unet_640x480_bs32 robo_unet_160x120_bs64}; do
     steps=20; if [[ $w == labelprop* ]]; then steps=300; fi
     RCV_LIBRARY=$GRAFT_REPO_ROOT/robocupvision_amd/$L timeout -k 10 300 python bench.py --workload $w --steps $steps --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$L', d['config']['workload'], d['ms_per_step'])" >> $O
   done
