@@ -147,8 +147,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
       case RCV_LOAD_GRAD_ENC: if (!GTWO) wstage_tile<RCV_LOAD_GRAD_ENC, UNR, true, false>(a.p, a.p_aux, a.p_c, pl, tid, NT, QP, cb0, a.CB, np_pix, a.fdWt4, a.Wt4, a.Wt, n * a.Hp, y0, x0, a.Hp, a.Wp, a.SP, bsum); break;
       default: if (!GTWO) wstage_tile<RCV_LOAD_GRAD_DEC, UNR, true, false>(a.p, a.p_aux, a.p_c, pl, tid, NT, QP, cb0, a.CB, np_pix, a.fdWt4, a.Wt4, a.Wt, n * a.Hp, y0, x0, a.Hp, a.Wp, a.SP, bsum); break;
     }
-    // (an NCHW image has <= 4 channels: only the folded tiles and the 16-channel-wide gathered tiles can meet it)
-    if ((FOLD || CAT == 16) && a.g_mode == RCV_LOAD_NCHW) {   // gathered tile from the NCHW image: one pixel (<= 4 planes) per thread
+    // (an NCHW image has <= 4 channels: only the 2-block folded tile and the 16-channel-wide gathered tiles can meet it)
+    if (((FOLD && NBF == 2) || (!FOLD && CAT == 16)) && a.g_mode == RCV_LOAD_NCHW) {   // gathered tile from the NCHW image: one pixel (<= 4 planes) per thread
       for (int pix0 = tid; pix0 < ng_pix; pix0 += UNR * NT) {
         float4 x[UNR];
 #pragma unroll
