@@ -519,7 +519,8 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
     pl->IH = 8 + 2 * d; pl->IW = 64 + 2 * d; pl->SP = 8; pl->SG = 1; pl->pl_floats = 0; pl->gl_floats = 0;
     return RCV_OK;
   }
-  const bool fold = CA <= 8 && cbt_want == 16 && !RCV_ENV("RCV_NO_FOLD");
+  // (an NCHW image with 4 channels does not fit the 2-block folded tile and the 5-block one carries no NCHW path: 16 x 16 tile)
+  const bool fold = CA <= 8 && cbt_want == 16 && !(nchw && 9 * CA > 32) && !RCV_ENV("RCV_NO_FOLD");
   if (fold) pl->tile = 9 * CA <= 32 ? 7 : 8;
   else {
     for (int t = 0; t < 7; ++t) if (kWT[t].cbt() == cbt_want && kWT[t].cat() == cat_want) pl->tile = t;

@@ -158,6 +158,40 @@ def test_filter_gradient_kernels_vs_fp64(N, H, W, Cin, Cout, s, modes):
     assert e <= 5e-7 and eb <= 5e-7, (lst.labels(h)[0], e, eb)
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,s,d", [(2, 48, 64, 3, 8, 1, 1), (2, 40, 56, 3, 8, 1, 2), (2, 48, 64, 3, 16, 1, 1), (2, 37, 53, 4, 16, 1, 1),
+                                               (2, 48, 64, 3, 32, 1, 1), (2, 48, 64, 4, 8, 1, 1), (1, 96, 128, 3, 16, 2, 1), (3, 24, 40, 2, 8, 1, 1)])
+@pytest.mark.parametrize("two", [False, True])
+def test_filter_gradient_nchw_image_vs_fp64(N, H, W, Cin, Cout, s, d, two):
+    """Filter gradient of a first layer: the gathered operand is the NCHW image itself (RCV_LOAD_NCHW, <= 4 channels) -- the vector-ALU
+    first-layer kernel (<= 3 channels into 8), the 2-block folded MFMA tile, and the 16-wide gathered tiles (4 channels, or more than 16
+    output channels); the pointwise operand plain or the two-tensor BatchNorm + ReLU backward load."""
+    from robocupvision_amd import _lib as L
+    h = L.handle(0)
+    gen = torch.Generator().manual_seed(3000 + H * W + Cout + Cin)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    G, P = _rand(gen, N, Cin, H, W), _rand(gen, N, Ho, Wo, Cout)
+    pc, Pa = _rand(gen, 5, Cout, scale=0.5), _rand(gen, N, Ho, Wo, Cout)
+    Gd, Pd, pcd, Pad = (v.to(DEV) for v in (G, P, pc, Pa))
+    dw = torch.full((Cout, Cin, 3, 3), float("nan"), device=DEV)
+    db = torch.full((Cout,), float("nan"), device=DEV)
+    mode2 = L.LOAD_GRAD_ENC if two else L.LOAD_PLAIN
+    op = L.make_op(L.OP_WGRAD, L.F_BIAS, n=N, h=H, w=W, cin=Cin, ho=Ho, wo=Wo, cout=Cout, stride=s, dil=d, inmode=L.LOAD_NCHW, inmode2=mode2,
+                   p_in=Gd.data_ptr(), p_in2=Pd.data_ptr(), p_in2_aux=Pad.data_ptr(), p_in2_c=pcd.data_ptr())
+    gy64 = _load_fp64(mode2, P, Pa, pc, L)
+    nb = L.op_workspace(h, op)
+    part = torch.zeros(max(nb // 4, 4), device=DEV)
+    op.p[L.RCV_P_PART] = part.data_ptr()
+    red = L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cin, cout=Cout, nsplit=op.i[L.RCV_I_NSPLIT], p_part=part.data_ptr(), p_out=dw.data_ptr(), p_bias=db.data_ptr())
+    lst = L.OpList([op, red])
+    lst.run(h, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = torch.nn.grad.conv2d_weight(G.double(), (Cout, Cin, 3, 3), gy64.permute(0, 3, 1, 2), stride=s, padding=d, dilation=d)
+    refb = gy64.sum((0, 1, 2))
+    e = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
+    eb = float((db.double().cpu() - refb).abs().max() / refb.abs().max())
+    assert e <= 5e-7 and eb <= 5e-7, (lst.labels(h)[0], e, eb)
+
+
 TCONV_SHAPES = [(2, 15, 20, 128, 64), (2, 30, 40, 64, 32), (2, 60, 80, 32, 16), (2, 120, 160, 16, 8), (3, 7, 9, 128, 64), (1, 33, 21, 64, 32),
                 (2, 24, 32, 32, 16), (4, 8, 10, 64, 64), (2, 20, 28, 16, 16), (1, 5, 6, 128, 128)]
 
