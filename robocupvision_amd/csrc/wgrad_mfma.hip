@@ -90,7 +90,9 @@ __device__ __forceinline__ void wstage_tile(const float* __restrict__ src, const
 // NBF == 0: regular mode (WN column blocks of 16 gathered channels, 9 taps each)
 // NBF  > 0: folded mode (WN must be 1): NBF column blocks over n = tap*CA + ca
 // GTWO: the gathered operand is a two-tensor gradient load (convT layer); otherwise the pointwise one may be.
-template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, bool SPEC, bool GTWO>
+// GNCHW: the gathered operand is the NCHW image (<= 4 channels: only the 2-block folded tile and the 16-channel-wide gathered tiles are
+// instantiated with it; compiled into every instantiation the path cost the hot ones a large part of their SGPR budget)
+template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, bool SPEC, bool GTWO, bool GNCHW = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) void wgrad_mfma_kernel(const WgradArgs a) {
   constexpr int NTC = WAVES_M * WAVES_N * WAVES_K * 64;   // MFMA (consumer) threads: waves 0..3
   constexpr int NT = NTC;                                 // staging threads: SPEC ? the next 4 (producer) waves : the same waves
@@ -147,8 +149,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
       case RCV_LOAD_GRAD_ENC: if (!GTWO) wstage_tile<RCV_LOAD_GRAD_ENC, UNR, true, false>(a.p, a.p_aux, a.p_c, pl, tid, NT, QP, cb0, a.CB, np_pix, a.fdWt4, a.Wt4, a.Wt, n * a.Hp, y0, x0, a.Hp, a.Wp, a.SP, bsum); break;
       default: if (!GTWO) wstage_tile<RCV_LOAD_GRAD_DEC, UNR, true, false>(a.p, a.p_aux, a.p_c, pl, tid, NT, QP, cb0, a.CB, np_pix, a.fdWt4, a.Wt4, a.Wt, n * a.Hp, y0, x0, a.Hp, a.Wp, a.SP, bsum); break;
     }
-    // (an NCHW image has <= 4 channels: only the 2-block folded tile and the 16-channel-wide gathered tiles can meet it)
-    if (((FOLD && NBF == 2) || (!FOLD && CAT == 16)) && a.g_mode == RCV_LOAD_NCHW) {   // gathered tile from the NCHW image: one pixel (<= 4 planes) per thread
+    if (GNCHW) {   // gathered tile from the NCHW image: one pixel (<= 4 planes) per thread
       for (int pix0 = tid; pix0 < ng_pix; pix0 += UNR * NT) {
         float4 x[UNR];
 #pragma unroll
@@ -480,6 +481,17 @@ static int wlaunch_inst(const WgradArgs& a, bool gtwo, dim3 grid, size_t lds, hi
     static size_t configured[RCV_MAX_DEVICES];
     RCV_ENSURE_LDS(kern, lds, dev, configured);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, a);
+  } else if (a.g_mode == RCV_LOAD_NCHW) {
+    constexpr bool CAN = NBF == 2 || (NBF == 0 && WN * WAVES_N == 1);       // tiles the planner gives an NCHW image (wmake_plan)
+    if constexpr (CAN) {
+      auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, SPEC, false, true>;
+      static size_t configured[RCV_MAX_DEVICES];
+      RCV_ENSURE_LDS(kern, lds, dev, configured);
+      hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, a);
+    } else {
+      rcv_set_error("wgrad: NCHW gathered operand on a tile without that path");
+      return RCV_E_ARG;
+    }
   } else {
     auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, SPEC, false>;
     static size_t configured[RCV_MAX_DEVICES];
