@@ -2,6 +2,7 @@
 """Benchmark of the hot path: training images/sec of ROBO-UNet 640x480, bs=32 per GPU (BASELINE.json).
 
     python bench.py                                   # 1 GPU
+    python bench.py --gpus N --steps K --warmup W     # N GPUs of this node: starts the N ranks below itself (fresh child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W     # one rank per GPU, RCCL gradient all-reduce
 
@@ -156,6 +157,14 @@ def cpu_baseline_labelprop(sd, B, H, W, budget_s=15.0):
         torch.set_num_threads(old)
 
 
+def kernel_family(label: str) -> str:
+    """Source kernel (__global__ template) behind an op label: conv_dma<2,5,4,1,4> and tconva_dma<...> are both conv_dma_kernel."""
+    m = re.match(r"t?conv[ma]?(s?)_(mfma|dma)<", label)
+    if m:
+        return "convs_mfma_kernel" if m.group(1) else "conv_%s_kernel" % m.group(2)
+    return label.split("<")[0] + "_kernel"
+
+
 def roofline_block(rows, ms_per_step, workload, batch_override, breakdown):
     """Per-kernel-family table from engine.profile_last rows -> the `roofline` object (dominant family) + per-layer roofline sums."""
     by = {}
@@ -179,6 +188,34 @@ def roofline_block(rows, ms_per_step, workload, batch_override, breakdown):
            "algorithmic_tflops": round(tf, 3), "algorithmic_gbs": round(gbs, 1),
            "arithmetic_intensity_flop_per_byte": round(d["flops"] / d["bytes"], 2) if d["bytes"] else None,
            "algorithmic_bytes_per_launch": int(d["bytes"] / d["launches"])}
+    # Pricing: FLOPs are those of the DIRECT convolution (the roofline is algorithmic).  A Winograd F(2x2,3x3) kernel executes
+    # 16/36 of those multiplications (plus tile padding), so for that family `frac` is the fraction of the roofline TIME, not matrix-pipe
+    # utilisation: `executed_tflops` / `mfma_pipe_frac` carry the latter.
+    out["flop_pricing"] = "direct-conv 2*MAC (algorithmic)"
+    if dom.startswith("conv_wino"):
+        out["flop_pricing"] += "; conv_wino executes 16/36 of them on the matrix pipe"
+        out["executed_tflops"] = round(tf * 16.0 / 36.0, 3)
+        out["mfma_pipe_frac"] = round(tf * 16.0 / 36.0 / PEAK_FP32_MFMA_TFLOPS, 4)
+    elif mfma_bound:
+        out["executed_tflops"] = round(tf, 3)
+        out["mfma_pipe_frac"] = out["frac"]
+    # the same figures per SOURCE kernel (all instantiations of one __global__ template together), largest first
+    fam = {}
+    for r in rows:
+        a = fam.setdefault(kernel_family(r["label"]), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "roof_ms": 0.0})
+        a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
+        a["roof_ms"] += bound_ms(r["flops"], r["bytes"])
+    top = []
+    for k in sorted(fam, key=lambda k: -fam[k]["ms"])[:8]:
+        a = fam[k]
+        if a["ms"] <= 0:
+            continue
+        fb = a["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12) >= a["bytes"] / (PEAK_HBM_GBS * 1e9)
+        top.append({"kernel": k, "launches_per_step": a["launches"], "ms_per_step": round(a["ms"], 4), "share": round(a["ms"] / total_ms, 4),
+                    "bound": "mfma" if fb else "hbm", "frac_of_own_roof": round(a["roof_ms"] / a["ms"], 4),
+                    "algorithmic_tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2),
+                    "algorithmic_gbs": round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)})
+    out["top_families"] = top
     tr, src = pmc_traffic(dom, workload) if not batch_override else (None, None)
     if tr is not None:
         out["traffic"] = int(tr)
@@ -221,15 +258,20 @@ def run_labelprop(args, dev, rank, world):
         for _ in range(args.warmup):
             net(x)
         torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record()
+        for k in range(args.steps):
             net(x)
+            marks[k + 1].record()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     ms = 1e3 * elapsed / args.steps
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     out = {"metric": "inference images/sec, LabelProp 160x120 8-channel frame-pair inputs, B=%d" % B,
            "value": round(B * world * args.steps / elapsed, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "ms_per_step": round(ms, 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": args.workload, "per_gpu_batch": B, "height": H, "width": W,
                       "step": "one eval-mode forward call (validLabelProp.py:132-135), NCHW in -> logits", "latency_ms": round(ms, 4),
                       "parallelism": "replicas%d" % world, "weights": "seeded random init (the shipped .pth does not travel)"}}
@@ -239,6 +281,61 @@ def run_labelprop(args, dev, rank, world):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_labelprop(sd, B, H, W)
     return out
+
+
+# Collective backend of the N > 1 runs: "nccl" (= RCCL over xGMI) is the product path.  RCV_DIST_BACKEND=gloo is a REHEARSAL knob: it lets
+# two ranks share the one GPU of a development box (RCCL refuses two ranks on one device), so that the whole N > 1 code path of this
+# file and of Trainer(distributed=True) runs before an 8-GPU node is available; its timings mean nothing.
+BACKEND = os.environ.get("RCV_DIST_BACKEND", "nccl")
+
+
+def _barrier(dist, local_rank):
+    if BACKEND == "nccl":
+        dist.barrier(device_ids=[local_rank])
+    else:
+        dist.barrier()
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process, relay rank 0's JSON line and the exit
+    code.  RCV_BENCH_LAUNCHER (tests) replaces the `python -m torch.distributed.run` prefix."""
+    import shlex
+    import subprocess
+    have = int(os.environ["RCV_BENCH_ASSUME_DEVICES"]) if os.environ.get("RCV_BENCH_ASSUME_DEVICES") else torch.cuda.device_count()
+    if have < n and BACKEND == "nccl":
+        print("bench.py: --gpus %d asked for, %d HIP device(s) visible" % (n, have), file=sys.stderr)
+        return 2
+    launcher = shlex.split(os.environ["RCV_BENCH_LAUNCHER"]) if os.environ.get("RCV_BENCH_LAUNCHER") \
+        else [sys.executable, "-m", "torch.distributed.run"]
+    cmd = launcher + ["--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                      os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():           # rank 0 prints ONE JSON line; anything else on stdout (launcher chatter) goes to stderr
+        try:
+            if ln.lstrip().startswith("{") and isinstance(json.loads(ln), dict):
+                line = ln
+                continue
+        except ValueError:
+            pass
+        print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    elif r.returncode == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return r.returncode
 
 
 def main():
@@ -257,12 +354,21 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table to stderr")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  It has made NO GPU call yet (device_count() does not
+        # initialise the device on this stack) and never re-executes itself: the ranks are fresh child processes.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed.run launcher (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py: no HIP device visible (the hot path has no CPU fallback)")
+    if BACKEND == "nccl" and local_rank >= n_dev:
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible); RCCL needs one device per rank" % (local_rank, n_dev))
+    local_rank %= n_dev          # (only the gloo rehearsal shares a device between ranks)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if args.workload.startswith("labelprop"):
@@ -271,12 +377,12 @@ def main():
         if world > 1:
             import torch.distributed as dist
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl")
+            dist.init_process_group(BACKEND)
             tt = torch.tensor([out["ms_per_step"]], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             out["ms_per_step"] = round(float(tt.item()), 4)
             out["value"] = round(out["config"]["per_gpu_batch"] * world / (out["ms_per_step"] * 1e-3), 2)
-            dist.barrier(device_ids=[local_rank])
+            _barrier(dist, local_rank)
             dist.destroy_process_group()
         if rank == 0:
             print(json.dumps(out))
@@ -291,7 +397,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # no device_id: eager communicator binding slows EVERY kernel of the process by ~7 % on this stack (measured: 10.27 vs 9.58
         # ms/step with the collectives stubbed out); the device is fixed by torch.cuda.set_device above, barriers name it explicitly
-        dist.init_process_group("nccl")
+        dist.init_process_group(BACKEND)
 
     import robocupvision_amd.model as M
     from robocupvision_amd.train import Trainer
@@ -306,8 +412,8 @@ def main():
     trainer = Trainer(model, class_weights=[1, 2, 6, 3, 2] if args.dice else [1, 10, 30, 10, 2], lr=1e-3, decay=1e-6,
                       distributed=dist is not None, use_dice=args.dice)
     if dist is not None:      # the first barrier builds the communicator: keep that out of the timed region
-        dist.barrier(device_ids=[local_rank])
-        dist.barrier(device_ids=[local_rank])
+        _barrier(dist, local_rank)
+        _barrier(dist, local_rank)
 
     use_graph = args.graph == 1
     step = trainer.step
@@ -318,15 +424,20 @@ def main():
     for _ in range(args.warmup):
         step(x, t)
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        _barrier(dist, local_rank)
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step device times (median), no host sync
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         step(x, t)
+        marks[k + 1].record()
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        _barrier(dist, local_rank)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    median_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -338,7 +449,8 @@ def main():
         "metric": "training images/sec, ROBO-UNet 640x480 bs=32/GPU" if args.workload == "robo_unet_640x480_bs32"
         else "training images/sec, " + args.workload,
         "value": round(B * world * args.steps / elapsed, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "ms_per_step_median": round(median_ms, 4),
+        "ms_per_step_min_max": [round(per_step[0], 4), round(per_step[-1], 4)], "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
                    "step": "fwd+CE/argmax+bwd+L1+Adam (train.py:43-74)", "parallelism": "dp%d" % world,
@@ -363,7 +475,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
-        dist.barrier(device_ids=[local_rank])
+        _barrier(dist, local_rank)
         dist.destroy_process_group()
 
 

@@ -395,8 +395,10 @@ __global__ __launch_bounds__(256) void cls_fwd16_kernel(const float* __restrict_
 // db[c] = sum_p dl[c][p];  optional decoder BN-backward statistics of d_up against t.
 // CE: d loss / d logits is recomputed from (t, r, W, b, target) instead of being read: RCV_OP_CE_BWD and its tensor disappear (the
 // logits are re-formed with the forward's FMA order, so the gradients are bit-identical to the unfused path).
+// Built for every class count 1..8 (trainer.py:126-132 / train.py:301: numClass = 5 - nb - ng - nr - nl; model.py:462 nClass) and
+// for 8 or 16 input channels; a thread keeps COUT x CIN filter-gradient accumulators, so the wide variants run one workgroup per SIMD set.
 template <int CIN, int COUT, bool FUSED, bool CE>
-__global__ __launch_bounds__(256, 2) void cls_bwd_kernel(const float* __restrict__ up, const float* __restrict__ dl, const float* __restrict__ w,
+__global__ __launch_bounds__(256, (CIN == 8 ? 2 : 1)) void cls_bwd_kernel(const float* __restrict__ up, const float* __restrict__ dl, const float* __restrict__ w,
                                float* __restrict__ dup, const float* __restrict__ t, const float* __restrict__ tc,
                                float* __restrict__ stat_part, float* __restrict__ w_part, int N, int HW, int stats,
                                const float* __restrict__ r, const float* __restrict__ rc, int mode2,
@@ -1170,6 +1172,26 @@ static inline int reduce_grid(const rcv_handle* h, size_t work_items, int block)
   return (int)g;
 }
 
+typedef void (*cls_bwd_fn)(const float*, const float*, const float*, float*, const float*, const float*, float*, float*, int, int, int,
+                           const float*, const float*, int, const int64_t*, const float*, const float*, const float*, const float*);
+
+template <int CIN, bool FUSED, bool CE>
+static cls_bwd_fn cls_bwd_pick(int cout) {
+  switch (cout) {
+    case 1: return cls_bwd_kernel<CIN, 1, FUSED, CE>;
+    case 2: return cls_bwd_kernel<CIN, 2, FUSED, CE>;
+    case 3: return cls_bwd_kernel<CIN, 3, FUSED, CE>;
+    case 4: return cls_bwd_kernel<CIN, 4, FUSED, CE>;
+    case 5: return cls_bwd_kernel<CIN, 5, FUSED, CE>;
+    case 6: return cls_bwd_kernel<CIN, 6, FUSED, CE>;
+    case 7: return cls_bwd_kernel<CIN, 7, FUSED, CE>;
+    case 8: return cls_bwd_kernel<CIN, 8, FUSED, CE>;
+  }
+  return nullptr;
+}
+
+// Every refusal that depends on the SHAPE of a record (channel counts, load modes, flags) sits in front of the `query` return: what
+// rcv_op_workspace / the planner accepts, the launch accepts.  Only operand pointers and workspace row counts are checked after it.
 int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuery* query) {
   const int N = op->i[RCV_I_N], H = op->i[RCV_I_H], W = op->i[RCV_I_W];
   const int Cin = op->i[RCV_I_CIN], Cout = op->i[RCV_I_COUT];
@@ -1192,11 +1214,11 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       break;
     }
     case RCV_OP_BN_FINALIZE: {
-      if (query) return RCV_OK;
       const double count = (double)N * op->i[RCV_I_HO] * op->i[RCV_I_WO];
+      RCV_CHECK_ARG(op->i[RCV_I_NPART] > 0 && Cout > 0 && count > 0, "bn_finalize: empty");
+      if (query) return RCV_OK;
       RCV_CHECK_ARG(op->p[RCV_P_PART] && op->p[RCV_P_OUT] && op->p[RCV_P_X0] && op->p[RCV_P_X1] && op->p[RCV_P_X4] && op->p[RCV_P_X5],
                     "bn_finalize: null operand");
-      RCV_CHECK_ARG(op->i[RCV_I_NPART] > 0 && Cout > 0 && count > 0, "bn_finalize: empty");
       hipLaunchKernelGGL(bn_finalize_kernel, dim3(Cout), dim3(256), 0, s, (const float*)op->p[RCV_P_PART], op->i[RCV_I_NPART], Cout, count,
                          (const float*)op->p[RCV_P_X0], (const float*)op->p[RCV_P_X1], (float*)op->p[RCV_P_X2], (float*)op->p[RCV_P_X3],
                          op->f[0], op->f[1], (op->flags & RCV_F_TRAINING) ? 1 : 0, (float*)op->p[RCV_P_OUT], (float*)op->p[RCV_P_X4],
@@ -1222,12 +1244,13 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       break;
     }
     case RCV_OP_COMBINE: {
+      const int m2 = op->i[RCV_I_INMODE2];
+      RCV_CHECK_ARG(Cout > 0 && Cout % 4 == 0, "combine: %d channels unsupported (multiple of 4)", Cout);
+      RCV_CHECK_ARG(m2 == RCV_LOAD_PLAIN || m2 == RCV_LOAD_AFFINE || m2 == RCV_LOAD_AFFINE_RELU, "combine: skip load mode %d unsupported", m2);
       if (query) return RCV_OK;
-      RCV_CHECK_ARG(Cout % 4 == 0 && op->p[RCV_P_IN] && op->p[RCV_P_IN_C] && op->p[RCV_P_IN2] && op->p[RCV_P_OUT], "combine: bad operand");
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN_C] && op->p[RCV_P_IN2] && op->p[RCV_P_OUT], "combine: null operand");
       const size_t n4 = (size_t)N * H * W * Cout / 4;
       const int g = stream_grid(h, n4, 256);
-      const int m2 = op->i[RCV_I_INMODE2];
-      RCV_CHECK_ARG(m2 == RCV_LOAD_PLAIN || m2 == RCV_LOAD_AFFINE || m2 == RCV_LOAD_AFFINE_RELU, "combine: skip load mode %d unsupported", m2);
       RCV_CHECK_ARG(m2 == RCV_LOAD_PLAIN || op->p[RCV_P_IN2_C], "combine: skip constants missing");
       const float* t = (const float*)op->p[RCV_P_IN]; const float* tc = (const float*)op->p[RCV_P_IN_C];
       const float* r = (const float*)op->p[RCV_P_IN2]; const float* rc = (const float*)op->p[RCV_P_IN2_C];
@@ -1241,26 +1264,28 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     case RCV_OP_CLS_FWD: {
       const bool fused = (op->flags & RCV_F_FUSED_UP) != 0, with_ce = (op->flags & RCV_F_FUSED_CE) != 0;
       const int gce = reduce_grid(h, (size_t)N * H * W, 256);      // with the loss: one partial row per workgroup, same grid as RCV_OP_CE_FWD
+      RCV_CHECK_ARG((Cin == 8 || Cin == 16) && Cout >= 1 && Cout <= CLS_MAX_OUT,
+                    "classifier: %d -> %d channels unsupported (8 or 16 input channels, 1..%d classes)", Cin, Cout, CLS_MAX_OUT);
+      const int mode2 = op->i[RCV_I_AUX0];
+      // i[RCV_I_AUX1]: channels of the skip tensor when it is narrower than the classifier input (0 = Cin)
+      const int rch = (fused && op->i[RCV_I_AUX1] > 0) ? op->i[RCV_I_AUX1] : Cin;
+      if (fused) {
+        RCV_CHECK_ARG(rch % 4 == 0 && rch >= 4 && rch <= Cin && (Cin == 8 || !with_ce), "classifier (fused decoder output): %d skip channels for %d inputs", rch, Cin);
+        RCV_CHECK_ARG(mode2 == RCV_LOAD_PLAIN || mode2 == RCV_LOAD_AFFINE || mode2 == RCV_LOAD_AFFINE_RELU, "classifier: skip load mode %d", mode2);
+      }
+      RCV_CHECK_ARG(!with_ce || (fused && Cout <= CE_MAX_C), "classifier + cross entropy: needs the fused decoder input and <= %d classes", CE_MAX_C);
       if (query) {
         if (with_ce) { query->n_part = gce; query->part_bytes = (size_t)gce * 3 * sizeof(float); }
         return RCV_OK;
       }
-      RCV_CHECK_ARG((Cin == 8 || Cin == 16) && Cout >= 1 && Cout <= CLS_MAX_OUT, "classifier: Cin=%d Cout=%d unsupported", Cin, Cout);
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_W] && op->p[RCV_P_OUT], "classifier: null operand");
       const int g = stream_grid(h, (size_t)N * H * W, 256);
       const float* tc = (const float*)op->p[RCV_P_IN_C]; const float* r = (const float*)op->p[RCV_P_X3]; const float* rc = (const float*)op->p[RCV_P_X4];
-      const int mode2 = op->i[RCV_I_AUX0];
       const int64_t* tgt = (const int64_t*)op->p[RCV_P_IN2]; const float* cw = (const float*)op->p[RCV_P_X0];
       float* part = (float*)op->p[RCV_P_PART]; uint8_t* am = (uint8_t*)op->p[RCV_P_X2];
-      // i[RCV_I_AUX1]: channels of the skip tensor when it is narrower than the classifier input (0 = Cin)
-      const int rch = (fused && op->i[RCV_I_AUX1] > 0) ? op->i[RCV_I_AUX1] : Cin;
-      if (fused) {
-        RCV_CHECK_ARG(tc && r && (mode2 == RCV_LOAD_PLAIN || rc), "classifier (fused decoder output): operands missing");
-        RCV_CHECK_ARG(rch % 4 == 0 && rch >= 4 && rch <= Cin && (Cin == 8 || !with_ce), "classifier (fused decoder output): %d skip channels for %d inputs", rch, Cin);
-        RCV_CHECK_ARG(mode2 == RCV_LOAD_PLAIN || mode2 == RCV_LOAD_AFFINE || mode2 == RCV_LOAD_AFFINE_RELU, "classifier: skip load mode %d", mode2);
-      }
+      if (fused) RCV_CHECK_ARG(tc && r && (mode2 == RCV_LOAD_PLAIN || rc), "classifier (fused decoder output): operands missing");
       if (with_ce) {
-        RCV_CHECK_ARG(fused && Cout <= CE_MAX_C && tgt && part && op->p[RCV_P_X1], "classifier + cross entropy: needs the fused decoder input, target, workspace, loss_out");
+        RCV_CHECK_ARG(tgt && part && op->p[RCV_P_X1], "classifier + cross entropy: needs target, workspace, loss_out");
         RCV_CHECK_ARG(op->i[RCV_I_NPART] == gce, "classifier + cross entropy: workspace rows %d != %d", op->i[RCV_I_NPART], gce);
         hipLaunchKernelGGL((cls_fwd_kernel<8, true, true>), dim3(gce), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_W], (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout, tc, r, rc, mode2, tgt, cw, part, am, rch);
         RCV_HIP(hipGetLastError());
@@ -1279,13 +1304,20 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       // partial rows: stats [g][2][Cin] in p[PART]; filter+bias [g][Cout*Cin+Cout] in p[X0]; then reduced in-op
       const int g = reduce_grid(h, (size_t)N * H * W, 256);
       const size_t wrow = (size_t)Cout * Cin + Cout;
+      const bool fused = (op->flags & RCV_F_FUSED_UP) != 0;
+      RCV_CHECK_ARG((Cin == 8 || Cin == 16) && Cout >= 1 && Cout <= CLS_MAX_OUT,
+                    "classifier backward: %d -> %d channels unsupported (8 or 16 input channels, 1..%d classes)", Cin, Cout, CLS_MAX_OUT);
+      RCV_CHECK_ARG(Cin == 8 || !fused, "classifier backward (fused decoder output): 8 input channels only (got %d)", Cin);
+      RCV_CHECK_ARG(!(op->flags & RCV_F_FUSED_CE) || (fused && op->i[RCV_I_STATS] == RCV_STATS_BWD_DEC),
+                    "classifier + cross entropy backward: needs the fused decoder input with its BatchNorm-backward statistics");
+      RCV_CHECK_ARG(!fused || op->i[RCV_I_STATS] == RCV_STATS_BWD_DEC, "classifier backward (fused decoder output): decoder statistics kind expected");
+      RCV_CHECK_ARG(op->i[RCV_I_STATS] == RCV_STATS_NONE || op->i[RCV_I_STATS] == RCV_STATS_BWD_DEC, "classifier backward: statistics kind %d unsupported",
+                    op->i[RCV_I_STATS]);
       if (query) {
         query->n_part = g;
         query->part_bytes = (size_t)g * (2 * Cin + wrow) * sizeof(float);
         return RCV_OK;
       }
-      RCV_CHECK_ARG(Cin == 8 && Cout == 5, "classifier backward: only 8 -> 5 is built (got %d -> %d)", Cin, Cout);
-      const bool fused = (op->flags & RCV_F_FUSED_UP) != 0;
       RCV_CHECK_ARG((fused || op->p[RCV_P_IN]) && op->p[RCV_P_IN2] && op->p[RCV_P_W] && op->p[RCV_P_OUT] && op->p[RCV_P_PART] && op->p[RCV_P_X1],
                     "classifier backward: null operand");
       RCV_CHECK_ARG(op->i[RCV_I_NPART] == g, "classifier backward: workspace rows %d != %d", op->i[RCV_I_NPART], g);
@@ -1299,22 +1331,21 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       const int64_t* tgt = (const int64_t*)op->p[RCV_P_IN2]; const float* cw = (const float*)op->p[RCV_P_X0];
       const float* bias = (const float*)op->p[RCV_P_BIAS]; const float* loss_out = (const float*)op->p[RCV_P_X5];
       const float* grad_out = (const float*)op->p[RCV_P_IN2_AUX];
+      cls_bwd_fn kern;
+      const float* dl = (const float*)op->p[RCV_P_IN2];
       if (with_ce) {
-        RCV_CHECK_ARG(fused && stats == RCV_STATS_BWD_DEC && r && (mode2 == RCV_LOAD_PLAIN || rc) && tgt && loss_out && grad_out,
-                      "classifier + cross entropy backward: operands missing");
-        hipLaunchKernelGGL((cls_bwd_kernel<8, 5, true, true>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)nullptr,
-                           (const float*)op->p[RCV_P_W], (float*)op->p[RCV_P_OUT], (const float*)op->p[RCV_P_EPI_AUX],
-                           (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats, r, rc, mode2, tgt, cw, bias, loss_out, grad_out);
+        RCV_CHECK_ARG(r && (mode2 == RCV_LOAD_PLAIN || rc) && tgt && loss_out && grad_out, "classifier + cross entropy backward: operands missing");
+        kern = cls_bwd_pick<8, true, true>(Cout);
+        dl = nullptr;
       } else if (fused) {
-        RCV_CHECK_ARG(stats == RCV_STATS_BWD_DEC && r && (mode2 == RCV_LOAD_PLAIN || rc), "classifier backward (fused decoder output): operands missing");
-        hipLaunchKernelGGL((cls_bwd_kernel<8, 5, true, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
-                           (const float*)op->p[RCV_P_W], (float*)op->p[RCV_P_OUT], (const float*)op->p[RCV_P_EPI_AUX],
-                           (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats, r, rc, mode2, tgt, cw, bias, loss_out, grad_out);
+        RCV_CHECK_ARG(r && (mode2 == RCV_LOAD_PLAIN || rc), "classifier backward (fused decoder output): operands missing");
+        kern = cls_bwd_pick<8, true, false>(Cout);
       } else {
-        hipLaunchKernelGGL((cls_bwd_kernel<8, 5, false, false>), dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN2],
-                           (const float*)op->p[RCV_P_W], (float*)op->p[RCV_P_OUT], (const float*)op->p[RCV_P_EPI_AUX],
-                           (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats, r, rc, mode2, tgt, cw, bias, loss_out, grad_out);
+        kern = Cin == 8 ? cls_bwd_pick<8, false, false>(Cout) : cls_bwd_pick<16, false, false>(Cout);
       }
+      hipLaunchKernelGGL(kern, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], dl, (const float*)op->p[RCV_P_W], (float*)op->p[RCV_P_OUT],
+                         (const float*)op->p[RCV_P_EPI_AUX], (const float*)op->p[RCV_P_EPI_C], stat_part, w_part, N, H * W, stats, r, rc, mode2, tgt,
+                         cw, bias, loss_out, grad_out);
       RCV_HIP(hipGetLastError());
       // dW -> p[X1] ([Cout][Cin]), db -> p[X2]
       hipLaunchKernelGGL(rows_reduce_kernel, dim3((int)wrow), dim3(256), 0, s, w_part, g, (int)wrow, (float*)op->p[RCV_P_X1], Cout * Cin,
@@ -1324,8 +1355,8 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     case RCV_OP_CE_FWD: {
       const int HW = H * W;
       const int g = reduce_grid(h, (size_t)N * HW, 256);
-      if (query) { query->n_part = g; query->part_bytes = (size_t)g * 3 * sizeof(float); return RCV_OK; }
       RCV_CHECK_ARG(Cout >= 1 && Cout <= CE_MAX_C, "cross entropy: %d classes unsupported (max %d)", Cout, CE_MAX_C);
+      if (query) { query->n_part = g; query->part_bytes = (size_t)g * 3 * sizeof(float); return RCV_OK; }
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_PART] && op->p[RCV_P_OUT], "cross entropy: null operand");
       RCV_CHECK_ARG(op->i[RCV_I_NPART] == g, "cross entropy: workspace rows %d != %d", op->i[RCV_I_NPART], g);
       hipLaunchKernelGGL(ce_fwd_kernel, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const int64_t*)op->p[RCV_P_IN2],
@@ -1336,8 +1367,8 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       break;
     }
     case RCV_OP_CE_BWD: {
-      if (query) return RCV_OK;
       RCV_CHECK_ARG(Cout >= 1 && Cout <= CE_MAX_C, "cross entropy: %d classes unsupported", Cout);
+      if (query) return RCV_OK;
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_X0] && op->p[RCV_P_X1] && op->p[RCV_P_OUT], "cross entropy backward: null operand");
       const int g = stream_grid(h, (size_t)N * H * W, 256);
       hipLaunchKernelGGL(ce_bwd_kernel, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const int64_t*)op->p[RCV_P_IN2],
@@ -1346,8 +1377,9 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       break;
     }
     case RCV_OP_POOL_FWD: {
+      RCV_CHECK_ARG(Cout > 0 && Cout % 4 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool: C=%d H=%d W=%d unsupported", Cout, H, W);
+      RCV_CHECK_ARG(op->i[RCV_I_INMODE] == RCV_LOAD_PLAIN || op->i[RCV_I_INMODE] == RCV_LOAD_AFFINE, "maxpool: load mode %d unsupported", op->i[RCV_I_INMODE]);
       if (query) return RCV_OK;
-      RCV_CHECK_ARG(Cout % 4 == 0 && H % 2 == 0 && W % 2 == 0, "maxpool: C=%d H=%d W=%d unsupported", Cout, H, W);
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_OUT], "maxpool: null operand");
       const int g = stream_grid(h, (size_t)N * (H / 2) * (W / 2) * (Cout / 4), 256);
       if (op->i[RCV_I_INMODE] == RCV_LOAD_PLAIN)
@@ -1432,17 +1464,18 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       break;
     }
     case RCV_OP_ADD_SLICE: {
-      if (query) return RCV_OK;
       const int Ca = Cin;
-      RCV_CHECK_ARG(Ca % 4 == 0 && Cout % 4 == 0 && Ca <= Cout && op->p[RCV_P_OUT] && op->p[RCV_P_IN], "add_slice: bad operand");
+      RCV_CHECK_ARG(Ca > 0 && Ca % 4 == 0 && Cout % 4 == 0 && Ca <= Cout, "add_slice: %d channels into %d unsupported", Ca, Cout);
+      if (query) return RCV_OK;
+      RCV_CHECK_ARG(op->p[RCV_P_OUT] && op->p[RCV_P_IN], "add_slice: null operand");
       const size_t npix = (size_t)N * H * W;
       hipLaunchKernelGGL(add_slice_kernel, dim3(stream_grid(h, npix * (Ca / 4), 256)), dim3(256), 0, s, (float*)op->p[RCV_P_OUT], Cout,
                          (const float*)op->p[RCV_P_IN], (const float*)op->p[RCV_P_IN_C], Ca, npix, op->i[RCV_I_INMODE]);
       break;
     }
     case RCV_OP_CONFUSION: {
-      if (query) return RCV_OK;
       RCV_CHECK_ARG(Cout >= 1 && Cout <= 8 && N > 0 && H > 0 && W > 0, "confusion: %d classes unsupported (max 8)", Cout);
+      if (query) return RCV_OK;
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_OUT], "confusion: null operand");
       int gx = ceil_div(H * W, 256 * 8);
       if (gx > 64) gx = 64;
@@ -1451,8 +1484,9 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       break;
     }
     case RCV_OP_MATERIALIZE: {
+      RCV_CHECK_ARG(Cout > 0 && Cout % 4 == 0, "materialize: %d channels unsupported (multiple of 4)", Cout);
       if (query) return RCV_OK;
-      RCV_CHECK_ARG(Cout % 4 == 0 && op->p[RCV_P_IN] && op->p[RCV_P_OUT], "materialize: bad operand");
+      RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_OUT], "materialize: null operand");
       RCV_CHECK_ARG(op->i[RCV_I_INMODE] == RCV_LOAD_PLAIN || op->p[RCV_P_IN_C], "materialize: constants missing");
       const size_t n4 = (size_t)N * H * W * Cout / 4;
       hipLaunchKernelGGL(materialize_kernel, dim3(stream_grid(h, n4, 256)), dim3(256), 0, s, (const float*)op->p[RCV_P_IN],
@@ -1486,8 +1520,8 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     case RCV_OP_DICE_FWD: {
       const int HW = H * W;
       const int g = reduce_grid(h, (size_t)N * HW, 256);
-      if (query) { query->n_part = g; query->part_bytes = (size_t)g * DICE_ROW * sizeof(float); return RCV_OK; }
       RCV_CHECK_ARG(Cout >= 2 && Cout <= CE_MAX_C, "dice loss: %d classes unsupported (2..%d)", Cout, CE_MAX_C);
+      if (query) { query->n_part = g; query->part_bytes = (size_t)g * DICE_ROW * sizeof(float); return RCV_OK; }
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_PART] && op->p[RCV_P_OUT], "dice loss: null operand");
       RCV_CHECK_ARG(op->i[RCV_I_NPART] == g, "dice loss: workspace rows %d != %d", op->i[RCV_I_NPART], g);
       hipLaunchKernelGGL(dice_fwd_kernel, dim3(g), dim3(256), 0, s, (const float*)op->p[RCV_P_IN], (const int64_t*)op->p[RCV_P_IN2], N, Cout,
@@ -1498,8 +1532,8 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       break;
     }
     case RCV_OP_DICE_BWD: {
-      if (query) return RCV_OK;
       RCV_CHECK_ARG(Cout >= 2 && Cout <= CE_MAX_C, "dice loss: %d classes unsupported", Cout);
+      if (query) return RCV_OK;
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_IN2] && op->p[RCV_P_X0] && op->p[RCV_P_X1] && op->p[RCV_P_OUT], "dice loss backward: null operand");
       hipLaunchKernelGGL(dice_bwd_kernel, dim3(stream_grid(h, (size_t)N * H * W, 256)), dim3(256), 0, s, (const float*)op->p[RCV_P_IN],
                          (const int64_t*)op->p[RCV_P_IN2], (const float*)op->p[RCV_P_X0], (const float*)op->p[RCV_P_X1], N, Cout, H * W,
@@ -1507,16 +1541,16 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       break;
     }
     case RCV_OP_NHWC_TO_NCHW: {
-      if (query) return RCV_OK;
       RCV_CHECK_ARG(Cin == 8 && Cout >= 1 && Cout <= 8, "nhwc_to_nchw: %d -> %d channels unsupported (8 padded channels)", Cin, Cout);
+      if (query) return RCV_OK;
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_OUT], "nhwc_to_nchw: null operand");
       hipLaunchKernelGGL(nhwc_to_nchw_kernel<8>, dim3(stream_grid(h, (size_t)N * H * W, 256)), dim3(256), 0, s, (const float*)op->p[RCV_P_IN],
                          (const float*)op->p[RCV_P_BIAS], (float*)op->p[RCV_P_OUT], N, H * W, Cout);
       break;
     }
     case RCV_OP_NCHW_TO_NHWC: {
-      if (query) return RCV_OK;
       RCV_CHECK_ARG(Cout == 8 && Cin >= 1 && Cin <= 8, "nchw_to_nhwc: %d -> %d channels unsupported (8 padded channels)", Cin, Cout);
+      if (query) return RCV_OK;
       RCV_CHECK_ARG(op->p[RCV_P_IN] && op->p[RCV_P_OUT], "nchw_to_nhwc: null operand");
       hipLaunchKernelGGL(nchw_to_nhwc_kernel<8>, dim3(stream_grid(h, (size_t)N * H * W, 256)), dim3(256), 0, s, (const float*)op->p[RCV_P_IN],
                          (float*)op->p[RCV_P_OUT], N, H * W, Cin);

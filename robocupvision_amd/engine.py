@@ -186,6 +186,7 @@ class Plan:
         self.side_mode = "all"              # one of Engine.SIDE_MODES
         self.side_ms = None                  # backward ms under each of Engine.SIDE_MODES, from that measurement
         self.bytes = 0
+        self.pinned = 0                      # > 0: referenced by a captured hipGraph -- never evicted
 
 
 PLAN_BYTES_BUDGET = 96 << 30      # cached plans beyond this many bytes of engine buffers are dropped, least recently used first
@@ -353,7 +354,7 @@ class Engine:
         def only_consumer_is_cls1x1(idx: int) -> bool:
             users = [nd for nd in nodes if any(nd.d.get(k) == ("node", idx) for k in ("src", "skip", "add"))]
             return (len(users) == 1 and users[0].op == "cls" and tuple(users[0].d["weight"].shape[2:]) == (1, 1)
-                    and users[0].d["weight"].shape[0] == 5)
+                    and 1 <= users[0].d["weight"].shape[0] <= 8)
 
         # =============================== forward ===============================
         for node in nodes:
@@ -789,6 +790,10 @@ class Engine:
                     op.flags |= L.F_SIDE_STREAM
         plan.fwd = L.OpList(fwd)
         plan.bwd = L.OpList(bwd)
+        # plan-time validation: the library answers a query for a record exactly when it would launch it (every shape refusal sits in
+        # front of the query return), so an unsupported layer raises HERE with the library's message, not at the first backward
+        plan.fwd.labels(self.handle)
+        plan.bwd.labels(self.handle)
         return plan
 
     # ------------------------------------------------------------------ execution
@@ -812,13 +817,18 @@ class Engine:
                 if total <= self.plan_bytes_budget:
                     break
                 pl = self.plans[k]
-                if pl is plan or (self._last is not None and pl is self._last[0]):
-                    continue
+                if pl is plan or pl.pinned or (self._last is not None and pl is self._last[0]):
+                    continue          # (pinned: a live hipGraph replays raw pointers into this plan's buffers, Trainer.capture)
                 total -= pl.bytes
                 del self.plans[k]
         else:
             self.plans.move_to_end(key)
         return plan
+
+    def invalidate(self):
+        """Parameters or BatchNorm buffers were written behind the engine's back (``.data`` edits, raw-pointer kernels, a graph replay):
+        the next eval-mode forward re-derives the packed filters and BatchNorm constants instead of reusing its cached head."""
+        self.params_dirty = True
 
     def forward(self, inputs: Sequence[torch.Tensor], training: bool) -> torch.Tensor:
         for t in inputs:
@@ -1053,6 +1063,8 @@ class Engine:
         b.p[L.RCV_P_X5] = loss_out.data_ptr()
         b.p[L.RCV_P_IN2_AUX] = gone.data_ptr()
         plan.ce = {"fwd": L.OpList(fops), "bwd": L.OpList(bops), "kf": kf[0], "kb": kb[0], "loss_out": loss_out, "argmax": argmax}
+        plan.ce["fwd"].labels(self.handle)          # (plan-time validation, as in _build)
+        plan.ce["bwd"].labels(self.handle)
         return plan.ce
 
     def forward_ce(self, inputs: Sequence[torch.Tensor], targets: torch.Tensor, weight: Optional[torch.Tensor]):

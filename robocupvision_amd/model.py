@@ -77,7 +77,31 @@ def _bn_modules(m: nn.Module):
     return [x for x in m.modules() if isinstance(x, nn.BatchNorm2d)]
 
 
-class _BlockMixin:
+class _EngineOwner:
+    """Mixed into every module that can own an Engine.  The engine caches, per eval plan, everything that depends on the parameters
+    only (packed filters, BatchNorm constants) and re-derives it when it can SEE a change: its own kernels wrote parameters
+    (``params_dirty``) or a torch in-place op bumped a tensor's version counter.  Writes through ``.data`` (``p.data.mul_()``, the
+    reference's ``pruneModel``: ``param = param.data; param[...] = 0``, model.py:626-640) bump no counter, so the cache is ALSO dropped
+    at every ``.train()`` / ``.eval()`` call and after ``load_state_dict`` -- the reference's scripts call ``model.eval()`` at the top
+    of every validation pass (train.py:104, trainer.py:162-171).  A caller that edits ``.data`` BETWEEN two eval-mode forwards without
+    calling ``.eval()`` again must call ``invalidate()`` itself."""
+
+    def invalidate(self):
+        eng = self.__dict__.get("_engine")
+        if eng is not None:
+            eng.invalidate()
+
+    def train(self, mode: bool = True):
+        self.invalidate()
+        return super().train(mode)
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self.invalidate()
+        return out
+
+
+class _BlockMixin(_EngineOwner):
     """Standalone call of a single block (NCHW in, NCHW out like the reference's blocks): the block
     becomes a one-node graph with an NHWC input and a materialised output."""
 
@@ -117,7 +141,7 @@ class Pool(nn.Module):
         return W * H * self.ch, W // self.stride, H // self.stride
 
 
-class Conv(nn.Module, _BlockMixin):
+class Conv(_BlockMixin, nn.Module):
     """bn(relu(conv3x3(x))) -- ReLU before BatchNorm (model.py:105-124)."""
 
     def __init__(self, inplanes, planes, size, stride=1):
@@ -149,7 +173,7 @@ class Conv(nn.Module, _BlockMixin):
         return self.size * self.size * W * H * self.inch * self.ch * 2 * ratio + W * H * self.ch * 4, W, H
 
 
-class ConvPoolSimple(nn.Module, _BlockMixin):
+class ConvPoolSimple(_BlockMixin, nn.Module):
     """relu(bn(conv(x))) with dilation (model.py:166-176): LabelProp inference and the PB_FCN encoder."""
 
     def __init__(self, inplanes, planes, size, stride, padding, dilation, bias, *_ignored):
@@ -173,7 +197,7 @@ class ConvPoolSimple(nn.Module, _BlockMixin):
         return self._block_forward(x)
 
 
-class ConvPool(nn.Module, _BlockMixin):
+class ConvPool(_BlockMixin, nn.Module):
     """relu(bn(pool(relu(conv1(x))))): a dilated 3x3 conv, then a stride-2 3x3 conv as the 'pool' (model.py:126-142)."""
 
     def __init__(self, inplanes, planes):
@@ -200,7 +224,7 @@ class ConvPool(nn.Module, _BlockMixin):
         return self._block_forward(x)
 
 
-class upSampleTransposeConv(nn.Module, _BlockMixin):
+class upSampleTransposeConv(_BlockMixin, nn.Module):
     """relu(bn(ConvTranspose2d(k3,s2,p1,op1)(x))) (model.py:178-199)."""
 
     def __init__(self, inplanes, planes):
@@ -291,7 +315,7 @@ class UltClassifier(nn.Module):
 # ------------------------------------------------------------------------------------------
 # ROBO_UNet (model.py:461-536)
 # ------------------------------------------------------------------------------------------
-class ROBO_UNet(nn.Module):
+class ROBO_UNet(_EngineOwner, nn.Module):
     def __init__(self, noScale=False, planes=8, nClass=5, depth=4, levels=2, bellySize=5, bellyPlanes=128, pool=False, v2=False,
                  classSize=1):
         super().__init__()
@@ -509,7 +533,7 @@ class DiceLoss(nn.Module):
 # ------------------------------------------------------------------------------------------
 # LabelProp (model.py:538-567), inference only
 # ------------------------------------------------------------------------------------------
-class LabelProp(nn.Module):
+class LabelProp(_EngineOwner, nn.Module):
     def __init__(self, numClass, numPlanes, dropout=0.0):
         super().__init__()
         self.pre = ConvPoolSimple(8, numPlanes // 4, 3, 1, 1, 1, False, dropout)
@@ -656,7 +680,7 @@ class Classifier(nn.Module):
         raise L.RcvError("Classifier is executed as part of PB_FCN's graph; standalone use is not built")
 
 
-class PB_FCN(nn.Module):
+class PB_FCN(_EngineOwner, nn.Module):
     """The older PB-FCN segmentation net of trainer.py (model.py:269-309): dilated conv->BN->ReLU encoder, three (four with
     noScale) transposed-conv decoder blocks with skip adds, 1x1 segmenter.  classify=1 (patch classification through the
     pooled head) is not built."""

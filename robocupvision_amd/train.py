@@ -127,6 +127,7 @@ class Trainer:
             # identical parameters on every rank before the first step
             for p in model.parameters():
                 dist.broadcast(p.data, 0)
+            model._get_engine().invalidate()        # (.data writes bump no version counter: a cached eval head would be stale)
 
     def set_prune_indices(self, prune_indices):
         """The list pruneModelNew(model.parameters()) returns (train.py:345-347): masks aligned with the parameters of dim() > 1."""
@@ -217,6 +218,13 @@ class Trainer:
         with torch.cuda.graph(graph):
             pred = self.step(static_x, static_t)
         opt._t -= 1                                     # the capture recorded the step, it did not run it
+        # the graph replays raw pointers into this plan's buffers: the plan must outlive it (LRU eviction skips pinned plans)
+        plan = eng._last[0]
+        plan.pinned += 1
+
+        class _Pin:
+            def __del__(self, plan=plan):
+                plan.pinned -= 1
 
         def step_fn(x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
             if x.data_ptr() != static_x.data_ptr():
@@ -225,14 +233,19 @@ class Trainer:
                 static_t.copy_(t)
             graph.replay()
             opt._t += 1
+            # the replayed kernels wrote parameters and BatchNorm buffers through raw pointers: no tensor version moved, so the
+            # engine is told explicitly (an eval forward after this must not reuse packed filters / BN constants of older weights)
+            eng.invalidate()
             return pred
         step_fn.graph = graph
+        step_fn._pin = _Pin()                           # released together with step_fn (and its graph)
         return step_fn
 
     @torch.no_grad()
     def evaluate(self, imgs: torch.Tensor, targets: torch.Tensor):
         """valid() forward (train.py:102-131): eval-mode BN, CE, arg-max mask."""
-        self.model.eval()
+        if self.model.training:
+            self.model.eval()
         pred = self.model(imgs)
         loss = self.criterion(pred, targets)
         return pred, loss, self.criterion.last_argmax

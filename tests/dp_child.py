@@ -29,12 +29,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("RCV_DIST_BACKEND", "nccl")      # "gloo": rehearsal with several ranks sharing this box's one GPU
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if a.mode == "dist":
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
+        dist.init_process_group(backend)
     import robocupvision_amd.model as M
     from robocupvision_amd.train import Trainer
 
@@ -67,7 +70,7 @@ def main():
         torch.save(out, a.out)
     if a.mode == "dist":
         import torch.distributed as dist
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=[local_rank]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 

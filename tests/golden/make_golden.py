@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 REF = "/root/reference"
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.environ.get("GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))      # GOLDEN_OUT: regenerate elsewhere (to compare)
 THREADS = 8
 
 
@@ -126,18 +126,21 @@ def grad_summary(model):
     return rows
 
 
-def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta, dice=False):
-    """The train.py:43-74 step on the reference, seeds as SURVEY.md 8(c)."""
+def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta, dice=False, n_class=5, weights=None):
+    """The train.py:43-74 step on the reference, seeds as SURVEY.md 8(c).  n_class / weights: train.py:301,309-313 (the --noBall /
+    --noGoal / --noRobot / --noLine flags drop classes and the matching entries of the weight vector)."""
     torch.manual_seed(12345678)
     model = ref.ROBO_UNet(**ctor_kwargs)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(1)
     x = torch.randn(B, 3, H, W, generator=g)
-    t = torch.randint(0, 5, (B, H, W), generator=g)
+    t = torch.randint(0, n_class, (B, H, W), generator=g)
+    if weights is None:
+        weights = [1, 2, 6, 3, 2] if dice else [1, 10, 30, 10, 2]
     if dice:        # train.py:309,315 (--useDice)
-        crit = ref.DiceLoss(torch.tensor([1, 2, 6, 3, 2], dtype=torch.float32))
+        crit = ref.DiceLoss(torch.tensor(weights, dtype=torch.float32))
     else:
-        crit = ref.CrossEntropyLoss2d(torch.tensor([1, 10, 30, 10, 2], dtype=torch.float32))
+        crit = ref.CrossEntropyLoss2d(torch.tensor(weights, dtype=torch.float32))
     decay, lr, transfer = 1e-6, 1e-3, 0
     opt = torch.optim.Adam([
         {'params': model.downPart[0:transfer].parameters(), 'lr': lr * 10},
@@ -159,8 +162,8 @@ def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta, dice=Fal
     gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters())))
     opt.step()
     _, pc = torch.max(pred, 1)
-    top2 = torch.topk(pred.detach(), 2, dim=1)[0]
-    margin = (top2[:, 0] - top2[:, 1])
+    top2 = torch.topk(pred.detach(), min(2, n_class), dim=1)[0]
+    margin = (top2[:, 0] - top2[:, 1]) if n_class > 1 else torch.full_like(top2[:, 0], 1e30)      # (one class: no second logit)
     sd1 = model.state_dict()
     model.eval()
     with torch.no_grad():
@@ -172,13 +175,13 @@ def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta, dice=Fal
         "sum_p": float(sum(v.double().sum() for k, v in sd0.items() if v.dtype.is_floating_point and "running" not in k)),
         "logits_sum": float(pred.double().sum()), "logits_abs_sum": float(pred.double().abs().sum()),
         "ce": float(ce), "reg": float(reg), "loss": float(loss), "grad_norm": gnorm,
-        "argmax_hist": [int((pc == c).sum()) for c in range(5)], "correct": int((pc == t).sum()),
+        "argmax_hist": [int((pc == c).sum()) for c in range(n_class)], "correct": int((pc == t).sum()),
         "n_margin_lt_1e-4": int((margin < 1e-4).sum()), "n_margin_lt_1e-5": int((margin < 1e-5).sum()),
         "min_margin": float(margin.min()),
         "bn0_running_mean": [float(v) for v in sd1["downPart.Level0.layers.Conv0.bn.running_mean"]],
         "bn0_running_var": [float(v) for v in sd1["downPart.Level0.layers.Conv0.bn.running_var"]],
         "eval_logits_sum": float(pred_eval.double().sum()),
-        "eval_argmax_hist": [int((torch.max(pred_eval, 1)[1] == c).sum()) for c in range(5)],
+        "eval_argmax_hist": [int((torch.max(pred_eval, 1)[1] == c).sum()) for c in range(n_class)],
         "grad_summary": gsum,
         "param_after_step_sum": {k: float(v.double().sum()) for k, v in sd1.items() if v.dtype.is_floating_point},
     }
@@ -188,9 +191,9 @@ def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta, dice=Fal
     torch.manual_seed(12345678)
     model64 = ref.ROBO_UNet(**ctor_kwargs).double()
     if dice:
-        crit64 = ref.DiceLoss(torch.tensor([1, 2, 6, 3, 2], dtype=torch.float64))
+        crit64 = ref.DiceLoss(torch.tensor(weights, dtype=torch.float64))
     else:
-        crit64 = ref.CrossEntropyLoss2d(torch.tensor([1, 10, 30, 10, 2], dtype=torch.float64))
+        crit64 = ref.CrossEntropyLoss2d(torch.tensor(weights, dtype=torch.float64))
     model64.train()
     pred64 = model64(x.double())
     ce64 = crit64(pred64, t)
@@ -202,6 +205,9 @@ def run_step(ref, ctor_kwargs, B, H, W, store_full, tag, out_npz, meta, dice=Fal
                  "grad_norm": float(torch.sqrt(sum((p.grad ** 2).sum() for p in model64.parameters()))),
                  "grad_summary": grad_summary(model64),
                  "max_logit_err_fp32_ref": float((pred64 - pred.double()).abs().max())}
+    if n_class != 5 or "nClass" in ctor_kwargs:
+        m["n_class"] = n_class
+        m["weights"] = [float(v) for v in weights]
     meta[tag] = m
     out_npz[tag + "/argmax"] = npy(pc).astype(np.uint8)
     out_npz[tag + "/eval_argmax"] = npy(torch.max(pred_eval, 1)[1]).astype(np.uint8)
@@ -302,8 +308,6 @@ def pbfcn(ref, big=True):
     """the PB_FCN / trainer.py path -- dilated conv->BN->ReLU encoder blocks in TRAINING mode, ConvPool, a whole
     trainer.py:205-221 step (CrossEntropyLoss2d [1,6,1.5,3,3], SGD lr .1 momentum .5 weight_decay 1e-3), and the flat float64
     parameter dump of paramSave.py."""
-    import io
-    import tempfile
     out, meta = {}, {}
     g = torch.Generator().manual_seed(4048)
     torch.manual_seed(9)
@@ -314,66 +318,7 @@ def pbfcn(ref, big=True):
     block_kat(ref, out, "cpsT_8_16_s2", ref.ConvPoolSimple(8, 16, 3, 2, 1, 1, False), torch.randn(2, 8, 12, 16, generator=g), 404)
 
     def step(tag, noScale, B, H, W, store_full, v2=False):
-        torch.manual_seed(12345678)
-        model = ref.PB_FCN_2(False, nClass=5) if v2 else ref.PB_FCN(32, 5, 1, noScale, 0)      # trainer.py:126-129
-        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
-        gg = torch.Generator().manual_seed(1)
-        x = torch.randn(B, 3, H, W, generator=gg)
-        t = torch.randint(0, 5, (B, H, W), generator=gg)
-        crit = ref.CrossEntropyLoss2d(torch.tensor([1, 6, 1.5, 3, 3], dtype=torch.float32))
-        opt = torch.optim.SGD([{'params': model.parameters()}], lr=1e-1, momentum=0.5, weight_decay=1e-3)
-        model.train()
-        losses = []
-        for it in range(2):          # two steps: the second one exercises the momentum buffer
-            opt.zero_grad()
-            pred = model(x)
-            loss = crit(pred, t)
-            loss.backward()
-            if it == 0:
-                pred0, gsum = pred.detach().clone(), grad_summary_some(model)
-                grads0 = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
-                none_grads = [k for k, p in model.named_parameters() if p.grad is None]
-                gnorm = float(torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads0.values())))
-            opt.step()
-            losses.append(float(loss))
-            if it == 0:
-                sd1 = {k: v.clone() for k, v in model.state_dict().items()}
-        sd2 = model.state_dict()
-        _, pc = torch.max(pred0, 1)
-        top2 = torch.topk(pred0, 2, dim=1)[0]
-        margin = top2[:, 0] - top2[:, 1]
-        model.eval()
-        with torch.no_grad():
-            pred_eval = model(x)
-        meta[tag] = {
-            "noScale": noScale, "v2": v2, "B": B, "H": H, "W": W, "threads": torch.get_num_threads(), "torch": torch.__version__,
-            "sd_hash_init": sd_hash(sd0), "sd_hash_after_step": sd_hash(sd1), "sd_hash_after_2_steps": sd_hash(sd2),
-            "loss": losses[0], "loss_step2": losses[1], "grad_norm": gnorm, "grad_summary": gsum, "none_grads": none_grads,
-            "logits_sum": float(pred0.double().sum()), "logits_abs_sum": float(pred0.double().abs().sum()),
-            "argmax_hist": [int((pc == c).sum()) for c in range(5)], "correct": int((pc == t).sum()),
-            "eval_logits_sum": float(pred_eval.double().sum()), "eval_logits_abs_sum": float(pred_eval.double().abs().sum()),
-            "param_after_step_sum": {k: float(v.double().sum()) for k, v in sd1.items() if v.dtype.is_floating_point},
-            "param_after_2_steps_sum": {k: float(v.double().sum()) for k, v in sd2.items() if v.dtype.is_floating_point},
-        }
-        out[tag + "/argmax"] = npy(pc).astype(np.uint8)
-        out[tag + "/near_tie_idx"] = np.nonzero(npy(margin).reshape(-1) < 1e-4)[0].astype(np.int32)
-        if store_full:
-            out[tag + "/x"] = npy(x); out[tag + "/t"] = npy(t).astype(np.int64)
-            out[tag + "/logits"] = npy(pred0); out[tag + "/eval_logits"] = npy(pred_eval)
-            for k, gr in grads0.items():
-                if gr.numel() <= 4096:
-                    out["%s/grad/%s" % (tag, k)] = npy(gr)
-                else:
-                    out["%s/grad_head/%s" % (tag, k)] = npy(gr.reshape(-1)[:64])
-            for k, v in sd1.items():
-                if "running" in k:
-                    out["%s/after/%s" % (tag, k)] = npy(v)
-        print(tag, "loss=%.8f / %.8f gnorm=%.8f hist=%s" % (losses[0], losses[1], gnorm, meta[tag]["argmax_hist"]))
-        return model
-
-    def grad_summary_some(model):
-        return {k: [float(p.grad.double().sum()), float(p.grad.double().abs().sum()), float(p.grad.double().norm())]
-                for k, p in model.named_parameters() if p.grad is not None}
+        return pbfcn_step(ref, out, meta, tag, noScale, B, H, W, store_full, v2)
 
     model = step("pbfcn_s_2x48x64", False, 2, 48, 64, True)
     step("pbfcn_l_1x64x96", True, 1, 64, 96, True)
@@ -381,6 +326,78 @@ def pbfcn(ref, big=True):
     if big:
         step("pbfcn_s_4x120x160", False, 4, 120, 160, False)
         step("pbfcn_l_2x240x320", True, 2, 240, 320, False)
+    pbfcn_tail(ref, model, out, meta)
+
+
+def pbfcn_step(ref, out, meta, tag, noScale, B, H, W, store_full, v2=False, num_class=5, weights=(1, 6, 1.5, 3, 3)):
+    """trainer.py:205-221, two iterations; num_class / weights as trainer.py:126,133-138 (--noBall ... drop classes)."""
+    def grad_summary_some(model):
+        return {k: [float(p.grad.double().sum()), float(p.grad.double().abs().sum()), float(p.grad.double().norm())]
+                for k, p in model.named_parameters() if p.grad is not None}
+
+    torch.manual_seed(12345678)
+    model = ref.PB_FCN_2(False, nClass=num_class) if v2 else ref.PB_FCN(32, num_class, 1, noScale, 0)      # trainer.py:126-129
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    gg = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 3, H, W, generator=gg)
+    t = torch.randint(0, num_class, (B, H, W), generator=gg)
+    crit = ref.CrossEntropyLoss2d(torch.tensor(list(weights), dtype=torch.float32))
+    opt = torch.optim.SGD([{'params': model.parameters()}], lr=1e-1, momentum=0.5, weight_decay=1e-3)
+    model.train()
+    losses = []
+    for it in range(2):          # two steps: the second one exercises the momentum buffer
+        opt.zero_grad()
+        pred = model(x)
+        loss = crit(pred, t)
+        loss.backward()
+        if it == 0:
+            pred0, gsum = pred.detach().clone(), grad_summary_some(model)
+            grads0 = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            none_grads = [k for k, p in model.named_parameters() if p.grad is None]
+            gnorm = float(torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads0.values())))
+        opt.step()
+        losses.append(float(loss))
+        if it == 0:
+            sd1 = {k: v.clone() for k, v in model.state_dict().items()}
+    sd2 = model.state_dict()
+    _, pc = torch.max(pred0, 1)
+    top2 = torch.topk(pred0, 2, dim=1)[0]
+    margin = top2[:, 0] - top2[:, 1]
+    model.eval()
+    with torch.no_grad():
+        pred_eval = model(x)
+    meta[tag] = {
+        "noScale": noScale, "v2": v2, "B": B, "H": H, "W": W, "threads": torch.get_num_threads(), "torch": torch.__version__,
+        "sd_hash_init": sd_hash(sd0), "sd_hash_after_step": sd_hash(sd1), "sd_hash_after_2_steps": sd_hash(sd2),
+        "loss": losses[0], "loss_step2": losses[1], "grad_norm": gnorm, "grad_summary": gsum, "none_grads": none_grads,
+        "logits_sum": float(pred0.double().sum()), "logits_abs_sum": float(pred0.double().abs().sum()),
+        "argmax_hist": [int((pc == c).sum()) for c in range(num_class)], "correct": int((pc == t).sum()),
+        "eval_logits_sum": float(pred_eval.double().sum()), "eval_logits_abs_sum": float(pred_eval.double().abs().sum()),
+        "param_after_step_sum": {k: float(v.double().sum()) for k, v in sd1.items() if v.dtype.is_floating_point},
+        "param_after_2_steps_sum": {k: float(v.double().sum()) for k, v in sd2.items() if v.dtype.is_floating_point},
+    }
+    out[tag + "/argmax"] = npy(pc).astype(np.uint8)
+    out[tag + "/near_tie_idx"] = np.nonzero(npy(margin).reshape(-1) < 1e-4)[0].astype(np.int32)
+    if store_full:
+        out[tag + "/x"] = npy(x); out[tag + "/t"] = npy(t).astype(np.int64)
+        out[tag + "/logits"] = npy(pred0); out[tag + "/eval_logits"] = npy(pred_eval)
+        for k, gr in grads0.items():
+            if gr.numel() <= 4096:
+                out["%s/grad/%s" % (tag, k)] = npy(gr)
+            else:
+                out["%s/grad_head/%s" % (tag, k)] = npy(gr.reshape(-1)[:64])
+        for k, v in sd1.items():
+            if "running" in k:
+                out["%s/after/%s" % (tag, k)] = npy(v)
+    if num_class != 5:
+        meta[tag]["num_class"] = num_class
+        meta[tag]["weights"] = [float(v) for v in weights]
+    print(tag, "loss=%.8f / %.8f gnorm=%.8f hist=%s" % (losses[0], losses[1], gnorm, meta[tag]["argmax_hist"]))
+    return model
+
+
+def pbfcn_tail(ref, model, out, meta):
+    import tempfile
     # paramSave.saveParams on the twice-stepped small model: flat float64 dump in state_dict order
     sys.path.insert(0, REF)
     import paramSave
@@ -394,6 +411,31 @@ def pbfcn(ref, big=True):
                           "head": [float(v) for v in flat[:8]], "tail": [float(v) for v in flat[-8:]]}
     np.savez_compressed(os.path.join(HERE, "pbfcn.npz"), **out)
     with open(os.path.join(HERE, "pbfcn.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def nclass(ref):
+    """Class counts other than 5 (train.py:301,312-313 / trainer.py:126,136-137: numClass = 5 - nb - ng - nr - nl and the weight
+    vector loses the dropped classes' entries; model.py:462 nClass) and the 16-plane net (a 16-channel classifier input)."""
+    out, meta = {}, {}
+    ROBO_S = dict(noScale=False, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128)
+    ROBO_L = dict(noScale=True, planes=8, depth=4, levels=2, bellySize=5, bellyPlanes=128)
+    W_CE, W_DICE, W_PB = [1, 10, 30, 10, 2], [1, 2, 6, 3, 2], [1, 6, 1.5, 3, 3]
+    keep = lambda w, drop: [v for k, v in enumerate(w) if k not in drop]      # class order: background, ball, robot, goal, line
+    run_step(ref, dict(ROBO_S, nClass=4), 2, 48, 64, True, "robo_s_c4_2x48x64", out, meta, n_class=4, weights=keep(W_CE, (1,)))        # --noBall
+    run_step(ref, dict(ROBO_L, nClass=2), 1, 48, 64, True, "robo_l_c2_1x48x64", out, meta, n_class=2, weights=keep(W_CE, (1, 2, 3)))   # only lines
+    run_step(ref, dict(ROBO_S, nClass=3), 2, 48, 64, True, "robo_s_c3_2x48x64_dice", out, meta, dice=True, n_class=3,
+             weights=keep(W_DICE, (1, 4)))                                                                                            # --noBall --noLine --useDice
+    run_step(ref, dict(ROBO_S, nClass=1), 2, 48, 64, True, "robo_s_c1_2x48x64", out, meta, n_class=1, weights=[1.0])
+    run_step(ref, dict(ROBO_S, nClass=8), 2, 48, 64, True, "robo_s_c8_2x48x64", out, meta, n_class=8, weights=[1, 10, 30, 10, 2, 4, 3, 5])
+    run_step(ref, dict(ROBO_S, planes=16), 2, 48, 64, True, "robo_p16_2x48x64", out, meta)
+    run_step(ref, dict(ROBO_S, planes=16, nClass=7), 1, 48, 64, True, "robo_p16_c7_1x48x64", out, meta, n_class=7, weights=[1, 10, 30, 10, 2, 4, 3])
+    run_step(ref, dict(ROBO_S, nClass=4), 4, 120, 160, False, "robo_s_c4_4x120x160", out, meta, n_class=4, weights=keep(W_CE, (1,)))
+    pbfcn_step(ref, out, meta, "pbfcn_s_c4_2x48x64", False, 2, 48, 64, True, num_class=4, weights=keep(W_PB, (1,)))
+    pbfcn_step(ref, out, meta, "pbfcn_l_c3_1x64x96", True, 1, 64, 96, True, num_class=3, weights=keep(W_PB, (1, 3)))
+    pbfcn_step(ref, out, meta, "pbfcn2_s_c4_2x48x64", False, 2, 48, 64, True, v2=True, num_class=4, weights=keep(W_PB, (1,)))
+    np.savez_compressed(os.path.join(HERE, "nclass.npz"), **out)
+    with open(os.path.join(HERE, "nclass.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
 
 
@@ -487,3 +529,5 @@ if __name__ == "__main__":
         pbfcn(ref)
     if "surface" in which:
         surface(ref)
+    if "nclass" in which:       # (round 3, not in the default list: the other files stay byte-identical)
+        nclass(ref)

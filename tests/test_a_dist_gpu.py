@@ -62,11 +62,9 @@ def test_world1_forced_collectives_bit_identical_to_plain_trainer(tmp_path):
     assert abs(float(plain["losses"][0]) - meta["loss"]) <= 1e-3 * abs(meta["loss"])
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node)")
-def test_world2_gradient_is_mean_of_per_shard_oracle_gradients(tmp_path):
+def _check_world2(d):
     from oracle import cpu_reference as O
     import robocupvision_amd.model as M
-    d = _run_child(tmp_path, "dist2", "dist", 2, ("--shard", "1", "--steps", "1"))
     assert d["world"] == 2
     kats = np.load(os.path.join(ROOT, "tests", "golden", "whole_net.npz"))
     meta = json.load(open(os.path.join(ROOT, "tests", "golden", "whole_net.json")))[TAG]
@@ -87,3 +85,35 @@ def test_world2_gradient_is_mean_of_per_shard_oracle_gradients(tmp_path):
         scale = float(ref.abs().max()) + 1e-12
         err = float((got - ref).abs().max()) / scale
         assert err <= 1e-2, "%s: exchanged gradient off by %.3e of its scale" % (n, err)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node)")
+def test_world2_gradient_is_mean_of_per_shard_oracle_gradients(tmp_path):
+    _check_world2(_run_child(tmp_path, "dist2", "dist", 2, ("--shard", "1", "--steps", "1")))
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_world2_rehearsal_two_ranks_share_the_gpu_over_gloo(tmp_path, overlap):
+    """The same world-size-2 check on a ONE-GPU box: both ranks use device 0 and exchange through gloo (RCCL refuses two ranks on one
+    device).  Everything but the collective's transport is the product path: Trainer(distributed=True), the bucketed backward, the
+    communication stream and its joins with the library's filter-gradient stream, grad_scale = 1/2 inside the optimizer launch."""
+    extra = ("--shard", "1", "--steps", "1") + (() if overlap else ("--no-overlap",))
+    _check_world2(_run_child(tmp_path, "gloo2_%d" % overlap, "dist", 2, extra, {"RCV_DIST_BACKEND": "gloo"}))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` (the driver's command shape, no launcher around it) starts its two ranks itself and prints ONE JSON
+    line for the whole job.  Rehearsed on this box's single GPU over gloo; on a multi-GPU node the same command runs over RCCL."""
+    env = dict(os.environ)
+    env.update({"RCV_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--workload", "robo_unet_160x120_bs64", "--batch", "4"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2" and out["config"]["global_batch"] == 8
+    assert out["scaling"] == "weak" and out["steps"] == 3 and out["value"] > 0
+    assert abs(out["value"] - 8 / (out["ms_per_step"] * 1e-3)) <= 1e-2 * out["value"]
+    assert "cpu_baseline" not in out and "roofline" in out

@@ -232,7 +232,8 @@ def test_eval_head_is_cached_and_invalidated():
     tr = Trainer(model, class_weights=CE_W, lr=1e-2, decay=1e-6)
 
     def eval_logits():
-        model.eval()
+        if model.training:         # (every .eval() call drops the cache on purpose -- see test_data_writes_... below)
+            model.eval()
         with torch.no_grad():
             return model(x).clone()
 
@@ -257,3 +258,94 @@ def test_eval_head_is_cached_and_invalidated():
         model.downPart.Level0.layers.Conv0.bn.running_var.mul_(2.0)
     c = eval_logits()
     assert not torch.equal(b, c) and torch.equal(c, fresh_logits())
+
+
+def _fresh_eval_logits(model, x):
+    torch.manual_seed(0)
+    m2 = M.ROBO_UNet().to(DEV)
+    m2.load_state_dict(model.state_dict())
+    m2.eval()
+    with torch.no_grad():
+        return m2(x).clone()
+
+
+def test_eval_after_graph_replay_sees_the_new_weights():
+    """A replayed hipGraph writes parameters and BatchNorm buffers through raw pointers: no tensor version moves.  The eval forward
+    after it must not reuse the packed filters / BatchNorm constants its cached head derived from the OLD weights
+    (capture -> eval -> replays -> eval == a fresh engine on the current state dict)."""
+    x, t = O.synthetic_batch(2, 48, 64, seed=3)
+    x, t = x.to(DEV), t.to(DEV)
+    model = build().to(DEV)
+    tr = Trainer(model, class_weights=CE_W, lr=1e-2, decay=1e-6)
+    for _ in range(3):
+        tr.step(x, t)
+    step = tr.capture(x, t)
+    step(x, t)
+    _, _, _ = tr.evaluate(x, t)
+    a = tr.evaluate(x, t)[0].clone()
+    assert torch.equal(a, _fresh_eval_logits(model, x))
+    model.train()
+    for _ in range(4):
+        step(x, t)
+    b = tr.evaluate(x, t)[0].clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(a, b)
+    assert torch.equal(b, _fresh_eval_logits(model, x))
+    # replay WITHOUT an intervening .train()/.eval() call: the flag set by step_fn is what invalidates
+    step(x, t)
+    model.training = False
+    for mod in model.modules():
+        mod.training = False
+    with torch.no_grad():
+        c = model(x).clone()
+    assert torch.equal(c, _fresh_eval_logits(model, x)) and not torch.equal(c, b)
+
+
+def test_data_writes_are_seen_at_the_next_eval_call():
+    """``p.data`` edits bump no version counter (the reference's pruneModel does exactly that, model.py:626-640).  The cache is
+    dropped at every .eval()/.train() call (the reference's scripts call model.eval() at the top of each validation pass) and by
+    invalidate(); without either, a .data edit between two eval forwards is the one documented blind spot."""
+    x, _ = O.synthetic_batch(2, 48, 64, seed=3)
+    x = x.to(DEV)
+    model = build().to(DEV).eval()
+    with torch.no_grad():
+        a = model(x).clone()
+        assert torch.equal(model(x), a)
+        w = model.downPart.Level1.layers.Conv0.conv.weight
+        v0 = w._version
+        w.data.mul_(0.5)                               # pruneModel-style write
+        model.segmenter.layers.Class.bias.data[1] = 3.0
+        assert w._version == v0                        # ... invisible to the version key
+        model.eval()                                   # what valid() does first
+        b = model(x).clone()
+        assert not torch.equal(a, b) and torch.equal(b, _fresh_eval_logits(model, x))
+        w.data.mul_(2.0)
+        model.invalidate()                             # explicit form
+        c = model(x).clone()
+        assert torch.equal(c, _fresh_eval_logits(model, x)) and not torch.equal(c, b)
+
+
+def test_plan_of_a_live_capture_is_not_evicted():
+    """LRU eviction of plans (PLAN_BYTES_BUDGET) skips a plan a captured hipGraph still replays into."""
+    x, t = O.synthetic_batch(2, 48, 64, seed=3)
+    x, t = x.to(DEV), t.to(DEV)
+    model = build().to(DEV)
+    tr = Trainer(model, class_weights=CE_W, lr=1e-3, decay=1e-6)
+    for _ in range(3):
+        tr.step(x, t)
+    step = tr.capture(x, t)
+    eng = model._get_engine()
+    plan = eng._last[0]
+    assert plan.pinned == 1
+    eng.plan_bytes_budget = 1                          # every other plan is over budget from here on
+    for hw in ((32, 48), (40, 56), (56, 64)):
+        xx, tt = O.synthetic_batch(2, *hw, seed=5)
+        tr.step(xx.to(DEV), tt.to(DEV))
+    assert any(pl is plan for pl in eng.plans.values())
+    step(x, t)                                         # still replays into live buffers
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in model.parameters())
+    del step
+    import gc
+    gc.collect()
+    assert plan.pinned == 0

@@ -27,12 +27,12 @@ def build(ctor):
 DICE_W = [1, 2, 6, 3, 2]        # train.py:309
 
 
-def hip_step(model, x, t, decay=1e-6, lr=1e-3, do_step=True, dice=False):
+def hip_step(model, x, t, decay=1e-6, lr=1e-3, do_step=True, dice=False, weights=None):
     """train.py:43-74 with the package's modules (stock Adam: the caller-side part of the step)."""
     if dice:
-        crit = M.DiceLoss(torch.tensor(DICE_W, dtype=torch.float32)).to(DEV)
+        crit = M.DiceLoss(torch.tensor(weights or DICE_W, dtype=torch.float32)).to(DEV)
     else:
-        crit = M.CrossEntropyLoss2d(torch.tensor(CE_W, dtype=torch.float32)).to(DEV)
+        crit = M.CrossEntropyLoss2d(torch.tensor(weights or CE_W, dtype=torch.float32)).to(DEV)
     opt = torch.optim.Adam([{"params": model.downPart[0:0].parameters(), "lr": lr * 10},
                             {"params": model.downPart[0:].parameters()}, {"params": model.PB.parameters()},
                             {"params": model.upPart.parameters()}, {"params": model.segmenter.parameters()}], lr=lr)

@@ -31,8 +31,8 @@ def test_conv_pool_block_training(pb_kats, name, cin, cout):
     _run_block(pb_kats, name, mod)
 
 
-def pb_step(model, x, t, opt=None):
-    crit = M.CrossEntropyLoss2d(torch.tensor(PB_W, dtype=torch.float32)).to(DEV)
+def pb_step(model, x, t, opt=None, weights=None):
+    crit = M.CrossEntropyLoss2d(torch.tensor(weights or PB_W, dtype=torch.float32)).to(DEV)
     if opt is None:
         opt = torch.optim.SGD([{"params": model.parameters()}], lr=1e-1, momentum=0.5, weight_decay=1e-3)
     model.train()
