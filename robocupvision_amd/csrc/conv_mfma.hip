@@ -461,7 +461,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   // one pixel per slot, so a pixel's XK channels are one contiguous 32/64-byte piece of its NHWC record and the address arithmetic,
   // the load transform and its constants are paid once per XK/4 steps instead of every step.
   const int XK = a.xk, xq_shift = XK == 16 ? 2 : 1, XQ = 1 << xq_shift, XSTEPS = XK / CK;
-  const int xtotal = npix << xq_shift;          // (pixel, quad) items of one input chunk; <= XMAX * NT (host)
+  const int xtotal = npix << xq_shift;          // (pixel, quad) items of one input chunk; <= XMAX * NT, or <= 2 * XMAX * NT with XK == 16 (host)
+  // A 16-channel chunk spans four pipeline steps, so its items may be staged in TWO phases that reuse the same register slots: phase 0
+  // (items [0, XMAX*NT)) is loaded in the group's first step and written in its second, phase 1 (the rest) loaded in the third and
+  // written in the fourth.  The large stride-2 tiles (5 x 81 input pixels) then read whole 64-byte halves of every pixel record in
+  // two passes instead of 32-byte quarters in four: with two input tensors the four passes of the co-resident workgroups did not
+  // survive in the 4 MiB L2 (round 2: 524 MB fetched per launch of the 32 -> 64 data gradient against 196 MB algorithmic).
+  const bool two_phase = xtotal > XMAX * NT;
 
   const TileInfo ti = decode_tile<KIND>(a, xcd_remap(blockIdx.x, a.total_tiles), COT);
   int nxt = 3, ntaps = 9;
@@ -507,9 +513,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   // ---- input stream: registers -> (load transform) -> xl[g & 1] as [pixel][XK + pad]
   float4 px[XMAX], pa[AMAX];
   float4 kx[5];                                  // load constants of this thread's quad for the chunk in px (requested with it)
-  int xsrc[XMAX];                                // element offset of (pixel, quad) in the NHWC tensor, channel chunk 0; < 0: outside the plane
+  int xsrc[2 * XMAX];                            // element offset of (pixel, quad) in the NHWC tensor, channel chunk 0; < 0: outside the plane
 #pragma unroll
-  for (int u = 0; u < XMAX; ++u) {
+  for (int u = 0; u < 2 * XMAX; ++u) {
     const int idx = tid + u * NT;
     const int pix = idx >> xq_shift, q = idx & (XQ - 1);
     const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
@@ -517,10 +523,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
     const bool ok = idx < xtotal && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
     xsrc[u] = ok ? (((ti.n * a.H + gy) * a.W + gx) * a.Cin + 4 * q) : -1;      // (host: N*H*W*Cin < 2^31)
   }
-  auto load_slot = [&](int g, int u) {
-    if (u * NT < xtotal) {                       // workgroup uniform: whole slots without items are skipped
+  auto load_slot = [&](int g, int u, bool ph1 = false) {
+    if ((u + (ph1 ? XMAX : 0)) * NT < xtotal) {  // workgroup uniform: whole slots without items are skipped
       // branch-free inside (an invalid item reads the chunk of element 0 and is masked in write_x)
-      const size_t off = (size_t)(xsrc[u] >= 0 ? xsrc[u] : 0) + g * XK;
+      const int src = ph1 ? xsrc[XMAX + u] : xsrc[u];
+      const size_t off = (size_t)(src >= 0 ? src : 0) + g * XK;
       px[u] = ld4(a.in + off);
       if (TWO) pa[TWO ? u : 0] = ld4(a.in_aux + off);
     }
@@ -533,12 +540,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
     for (int j = 0; j < 5; ++j)
       if (j < nkx) kx[j] = ld4(a.in_c + j * a.Cin + g * XK + 4 * (tid & (XQ - 1)));
   };
-  auto load_x = [&](int g) {
+  auto load_x = [&](int g, bool ph1 = false) {
 #pragma unroll
-    for (int u = 0; u < XMAX; ++u) load_slot(g, u);
-    load_consts(g);
+    for (int u = 0; u < XMAX; ++u) load_slot(g, u, ph1);
+    if (!ph1) load_consts(g);                    // the constants of the chunk stay in kx for its second phase
   };
-  auto write_x_mode = [&](auto mode_c, int buf, int g) {
+  auto write_x_mode = [&](auto mode_c, int buf, int g, bool ph1) {
     constexpr int MODE = decltype(mode_c)::value;
     float* xb = xl + buf * a.xl_floats;
     const int q = tid & (XQ - 1);                // NT is a multiple of XQ: the quad of a thread is the same in every slot
@@ -547,25 +554,26 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
     for (int j = 0; j < 5; ++j) k[j] = kx[j];
 #pragma unroll
     for (int u = 0; u < XMAX; ++u) {
-      if (u * NT < xtotal) {
-        const int idx = tid + u * NT;
+      const int v_ = u + (ph1 ? XMAX : 0);
+      if (v_ * NT < xtotal) {
+        const int idx = tid + v_ * NT;
         if (idx < xtotal) {
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (xsrc[u] >= 0) v = xform4<MODE>(px[u], pa[TWO ? u : 0], k);   // zero padding AFTER the transform
+          if ((ph1 ? xsrc[XMAX + u] : xsrc[u]) >= 0) v = xform4<MODE>(px[u], pa[TWO ? u : 0], k);   // zero padding AFTER the transform
           float* d = xb + (idx >> xq_shift) * S + 4 * q;
           d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
       }
     }
   };
-  auto write_x = [&](int buf, int g) {
+  auto write_x = [&](int buf, int g, bool ph1 = false) {
     if constexpr (TWO) {
-      if (a.in_mode == RCV_LOAD_GRAD_ENC) write_x_mode(std::integral_constant<int, RCV_LOAD_GRAD_ENC>{}, buf, g);
-      else write_x_mode(std::integral_constant<int, RCV_LOAD_GRAD_DEC>{}, buf, g);
+      if (a.in_mode == RCV_LOAD_GRAD_ENC) write_x_mode(std::integral_constant<int, RCV_LOAD_GRAD_ENC>{}, buf, g, ph1);
+      else write_x_mode(std::integral_constant<int, RCV_LOAD_GRAD_DEC>{}, buf, g, ph1);
     } else {
-      if (a.in_mode == RCV_LOAD_AFFINE) write_x_mode(std::integral_constant<int, RCV_LOAD_AFFINE>{}, buf, g);
-      else if (a.in_mode == RCV_LOAD_AFFINE_RELU) write_x_mode(std::integral_constant<int, RCV_LOAD_AFFINE_RELU>{}, buf, g);
-      else write_x_mode(std::integral_constant<int, RCV_LOAD_PLAIN>{}, buf, g);
+      if (a.in_mode == RCV_LOAD_AFFINE) write_x_mode(std::integral_constant<int, RCV_LOAD_AFFINE>{}, buf, g, ph1);
+      else if (a.in_mode == RCV_LOAD_AFFINE_RELU) write_x_mode(std::integral_constant<int, RCV_LOAD_AFFINE_RELU>{}, buf, g, ph1);
+      else write_x_mode(std::integral_constant<int, RCV_LOAD_PLAIN>{}, buf, g, ph1);
     }
   };
 
@@ -637,6 +645,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
   dma_w(0, 0);
   load_x(0);
   write_x(0, 0);
+  if (two_phase) { load_x(0, true); write_x(0, 0, true); }
   constexpr int JSPLIT = (KIND == KIND_GATHER || KIND == KIND_TALL) ? 5 : 2;
 #ifdef RCV_STAMPS
   RCV_STAMP(st_loop0);
@@ -663,11 +672,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
     // F(i+1) and X(g+1) are requested from inside the tap loop, one instruction per tap (an LDS-DMA instruction holds the wave's
     // issue for 60..100 cycles: spread out, the matrix pipe keeps running behind each of them).  The last step re-requests its own
     // slab into the retired buffer instead of branching.
-    const bool ldx = sub == 0 && g + 1 < ngroups;
+    const bool ph1 = sub >= 2;                     // second staging phase of the next chunk (two_phase: steps 2 and 3 of a 16-channel group)
+    const bool ldx = (sub == 0 || (two_phase && sub == 2)) && g + 1 < ngroups;
     const int fstep = i + 1 < nsteps ? i + 1 : i;
     constexpr bool SPREAD = KIND == KIND_GATHER;   // (all-parity transposed conv, 5-MFMA taps: measured 10 % slower spread out)
     if (!SPREAD) {
-      if (ldx) load_x(g + 1);
+      if (ldx) load_x(g + 1, ph1);
       dma_w(buf ^ 1, fstep);
     }
 #ifdef RCV_STAMPS
@@ -675,7 +685,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
 #endif
     const float* wb = wl + buf * WBUF;
     const float* xb = xl + (g & 1) * a.xl_floats + sub * CK;
-    const bool wx = (sub == 1 || XSTEPS == 1) && g + 1 < ngroups;
+    const bool wx = (sub == 1 || XSTEPS == 1 || (two_phase && sub == 3)) && g + 1 < ngroups;
     if (KIND == KIND_GATHER || KIND == KIND_TALL) {
       // Two operand register sets: the LDS reads of tap j+1 are issued one behind each of the first MFMAs of tap j (pinned with
       // sched_group_barrier: left alone, the compiler sinks them to the end of the tap and every tap starts with an exposed LDS
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
 #ifdef RCV_STAMPS
           RCV_STAMP(st_b); st_seg[3] += st_b - st_a; st_a = st_b;
 #endif
-          if (wx) write_x((g + 1) & 1, g + 1);
+          if (wx) write_x((g + 1) & 1, g + 1, ph1);
 #ifdef RCV_STAMPS
           RCV_STAMP(st_b); st_seg[4] += st_b - st_a; st_a = st_b;
 #endif
@@ -703,8 +713,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
         if (SPREAD && j < WU) dma_one(buf ^ 1, fstep, j < WU ? j : 0);           // F(i+1), one LDS-DMA instruction per tap
         if (SPREAD && j >= 5 && ldx) {                                           // X(g+1): registers, written to LDS in the next step
 #pragma unroll
-          for (int q = 0; q < XMAX / 4; ++q) load_slot(g + 1, (j - 5) * (XMAX / 4) + q);
-          if (j == 8) load_consts(g + 1);
+          for (int q = 0; q < XMAX / 4; ++q) load_slot(g + 1, (j - 5) * (XMAX / 4) + q, ph1);
+          if (j == 8 && !ph1) load_consts(g + 1);
         }
         mfma_tap(cur, ph);
         ph = ph_next;
@@ -726,12 +736,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv_dma_kernel(const C
       Ops o;
       int dy, dx, ph;
       for (int j = 0; j < ntaps; ++j) {
-        if (j == JSPLIT && wx) write_x((g + 1) & 1, g + 1);
+        if (j == JSPLIT && wx) write_x((g + 1) & 1, g + 1, ph1);
         tap_geom(j, dy, dx, ph);
         read_tap(o, wb, xb, j, dy, dx);
         mfma_tap(o, 0);
       }
-      if (ntaps <= JSPLIT && wx) write_x((g + 1) & 1, g + 1);
+      if (ntaps <= JSPLIT && wx) write_x((g + 1) & 1, g + 1, ph1);
     }
 #ifdef RCV_STAMPS
     RCV_STAMP(st_b); st_seg[5] += st_b - st_a; st_a = st_b;
@@ -979,7 +989,12 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
     };
     const size_t lds_room = (size_t)h->max_lds / 2;
     const int slots = 4;                                   // (pixel, quad) register slots per thread (an 8-slot variant of the kernel for the large stride-2 tiles measured 2.6x slower)
-    pl->xk = (CinP % 16 == 0 && npix * 4 <= tc.nt() * slots && lds_floats(16) * sizeof(float) <= lds_room) ? 16 : 8;
+    // (16-channel chunks may be staged in two phases through the same slots: twice the items, see conv_dma_kernel)
+    // -- for the two-tensor (gradient) loads only: measured on the 32 -> 64 stride-2 pair at 32x120x160, the data gradient went
+    // 0.127 -> 0.115 ms with its fetched bytes at the algorithmic 190 MB, the one-tensor forward launch (whose four passes did survive in L2)
+    // 0.090 -> 0.101 ms because the larger input buffers cost it the third resident workgroup
+    const bool two = mode == RCV_LOAD_GRAD_ENC || mode == RCV_LOAD_GRAD_DEC;
+    pl->xk = (CinP % 16 == 0 && npix * 4 <= tc.nt() * slots * (two ? 2 : 1) && lds_floats(16) * sizeof(float) <= lds_room) ? 16 : 8;
     pl->xl_floats = round_up(npix * conv_xpitch(pl->xk, xs), 4);
     floats = 2 * (size_t)pl->wl_floats + 2 * (size_t)pl->xl_floats + 5 * CinP + 16 + (size_t)tc.WAVES_N * 2 * tc.cot();
   } else {
