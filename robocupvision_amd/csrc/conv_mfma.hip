@@ -906,10 +906,12 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   pl->dma = 0;
   pl->first = 0;
   pl->wino = 0;
+  pl->small = 0;
   if (conv_wino_supported(h, op, pl->kind)) return conv_wino_plan(h, op, pl);
   RCV_CHECK_ARG(transposed || op->i[RCV_I_AUX0] != 2, "conv: a filter packed in the Winograd layout needs stride 1 / dilation 1");
   if (conv_first_supported(op, pl->kind)) return conv_first_plan(h, op, pl);
   if (convs_supported(h, op, pl->kind, CinP, pl->kind == KIND_TMERGED ? 4 * Cout : Cout)) return convs_make_plan(h, op, pl->kind, pl);
+  if (conv_small_supported(h, op, pl->kind)) return conv_small_plan(h, op, pl);
   pl->CK = (CinP % 8 == 0) ? 8 : 4;
   const int Q = pl->CK / 4;
   pl->CoutV = pl->kind == KIND_TMERGED ? 4 * Cout : Cout;
@@ -1037,6 +1039,8 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
     static const char* kn[] = {"conv", "tconv", "tconvm", "tconva"};
     if (pl.wino) {
       snprintf(query->label, sizeof(query->label), "conv_wino<64,%d>", 16 * pl.WN);
+    } else if (pl.small) {
+      snprintf(query->label, sizeof(query->label), "conv_small<%d>", op->i[RCV_I_DIL]);
     } else if (pl.first) {
       snprintf(query->label, sizeof(query->label), "conv_first<%d>", op->i[RCV_I_DIL]);
     } else if (pl.narrow) {
@@ -1089,6 +1093,7 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   RCV_CHECK_ARG(!(a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC) || a.epi_c, "conv: backward statistics need epi_c (scale, shift, mean)");
   if (pl.wino) return conv_wino_launch(pl, a, s);
   if (pl.first) return conv_first_launch(pl, a, s);
+  if (pl.small) return conv_small_launch(pl, a, s);
   if (pl.narrow) return convs_launch(pl, a, a.in_mode == RCV_LOAD_GRAD_ENC || a.in_mode == RCV_LOAD_GRAD_DEC, s);
   const dim3 grid(pl.grid);
   if (pl.dma) {

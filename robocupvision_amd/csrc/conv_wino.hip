@@ -156,7 +156,11 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
         tq[2][q] = r[2][q] - r[1][q];
         tq[3][q] = r[1][q] - r[3][q];
       }
-      float* o = vl + vbuf * W_VBUF + vt_c * W_VP + vt_tile;
+      // V image [xi][ci][tile], row pitch = 16 mod 32 (the B reads below).  The 32 lanes of one write access are 8 tiles x 4 channels:
+      // rows ci = 2, 3 would fall on the banks of rows 0, 1 (2-way conflict on all 16 writes of every item; with the raw-chunk and
+      // exchange accesses 32 % of the LDS-active cycles of round 2's profile), so they store tile t at t ^ 8 -- the B read of k-lane
+      // ci applies the same swap, every lane still gets ITS tile
+      float* o = vl + vbuf * W_VBUF + vt_c * W_VP + (vt_tile ^ ((vt_c >> 1) << 3));
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         o[(p * 4 + 0) * 4 * W_VP] = tq[p][0] - tq[p][2];
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
   int aoff[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) aoff[m] = l4 * W_COT + ((m * 16 + l15) ^ ((l4 & 1) << 4));
-  const int boff = l4 * W_VP + l15;
+  const int boff = l4 * W_VP + (l15 ^ ((l4 >> 1) << 3));        // (tile swap of rows 2, 3: see v_transform)
 
   const int nsteps = a.CinP / W_CK, ngroups = a.CinP / W_XK;
   // ---- prologue

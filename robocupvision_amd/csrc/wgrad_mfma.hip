@@ -92,7 +92,11 @@ __device__ __forceinline__ void wstage_tile(const float* __restrict__ src, const
 // GTWO: the gathered operand is a two-tensor gradient load (convT layer); otherwise the pointwise one may be.
 // GNCHW: the gathered operand is the NCHW image (<= 4 channels: only the 2-block folded tile and the 16-channel-wide gathered tiles are
 // instantiated with it; compiled into every instantiation the path cost the hot ones a large part of their SGPR budget)
-template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, bool SPEC, bool GTWO, bool GNCHW = false>
+// CT_S / CT_IW / CT_SG > 0 (wave-specialised 64 x 64 tile only): the stride, the width of the gathered LDS tile and its pixel pitch are
+// compile-time values (dilation 1), so that the 18 gathered-operand reads of a k-step are ONE address register plus immediate offsets
+// instead of one address add each (round 2 counted 22 vector instructions per 36-MFMA k-step in the consumer waves, 20 of them adds).
+template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, bool SPEC, bool GTWO, bool GNCHW = false, int CT_S = 0, int CT_IW = 0,
+          int CT_SG = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) void wgrad_mfma_kernel(const WgradArgs a) {
   constexpr int NTC = WAVES_M * WAVES_N * WAVES_K * 64;   // MFMA (consumer) threads: waves 0..3
   constexpr int NT = NTC;                                 // staging threads: SPEC ? the next 4 (producer) waves : the same waves
@@ -262,6 +266,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
   }
   const int ksteps = np_pix / 4;
   const int a_lane = l4 * a.SP + (wave_m * WM) * 16 + l15;
+  constexpr bool CT = CT_IW > 0;
+  const int g_lane = (l4 * (CT ? CT_S : s)) * (CT ? CT_SG : a.SG) + (wave_n * WN) * 16 + l15;      // CT: the lane part of every gathered read
 
   // The k-step slice of this wave (wave_k is the same for all its lanes: made a scalar so that the loop and its pixel arithmetic run
   // on the scalar unit).
@@ -271,9 +277,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64 + (SPEC ? 256 : 0)) 
     const int ty = fd_div(p0, a.fdWt4), tx = p0 - ty * a.Wt4;
 #pragma unroll
     for (int m = 0; m < WM; ++m) av[m] = pl[p0 * a.SP + a_lane + m * 16];
-    const float* gj = gl + ((ty * s) * a.IW + tx * s) * a.SG;
+    if constexpr (CT && !FOLD) {
+      const float* gb = gl + ((ty * CT_S) * CT_IW + tx * CT_S) * CT_SG + g_lane;
 #pragma unroll
-    for (int t = 0; t < NACC; ++t) bv[t] = gj[loff[t]];
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int nn = 0; nn < WN; ++nn) bv[t * WN + nn] = gb[((t / 3) * CT_IW + (t % 3)) * CT_SG + nn * 16];      // immediates
+    } else {
+      const float* gj = gl + ((ty * s) * a.IW + tx * s) * a.SG;
+#pragma unroll
+      for (int t = 0; t < NACC; ++t) bv[t] = gj[loff[t]];
+    }
   };
   auto mfma_ops = [&](const float (&av)[WM], const float (&bv)[NACC]) {
 #pragma unroll
@@ -473,9 +487,27 @@ static const WTile kWT[] = {
     {1, 1, 1, 1, 4, 5, 0},  // 8: 16 x (9 taps x <=8 ch folded into 5 blocks)
 };
 
+// the 64 x 64 producer/consumer tile with compile-time gathered-tile geometry (the shapes the planner picks for the 64- and
+// 128-channel layers of the BASELINE planes on a 256-CU part); any other geometry runs the run-time-pitch instantiation
+template <bool GTWO, int CT_S, int CT_IW, int CT_SG>
+static int wlaunch_ct(const WgradArgs& a, dim3 grid, size_t lds, hipStream_t s, int dev) {
+  auto kern = wgrad_mfma_kernel<2, 2, 2, 2, 1, 0, true, GTWO, false, CT_S, CT_IW, CT_SG>;
+  static size_t configured[RCV_MAX_DEVICES];
+  RCV_ENSURE_LDS(kern, lds, dev, configured);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+  RCV_HIP(hipGetLastError());
+  return RCV_OK;
+}
+
 template <int WM, int WN, int WAVES_M, int WAVES_N, int WAVES_K, int NBF, bool SPEC>
 static int wlaunch_inst(const WgradArgs& a, bool gtwo, dim3 grid, size_t lds, hipStream_t s, int dev) {
   constexpr int NT = WAVES_M * WAVES_N * WAVES_K * 64 + (SPEC ? 256 : 0);     // consumer (+ producer) waves
+  if constexpr (SPEC && WAVES_K == 1 && NBF == 0) {
+    if (a.dil == 1 && a.g_mode != RCV_LOAD_NCHW && !RCV_ENV("RCV_WGRAD_NO_CT")) {
+      if (a.stride == 1 && a.IW == 22 && a.SG == 80 && !gtwo) return wlaunch_ct<false, 1, 22, 80>(a, grid, lds, s, dev);
+      if (a.stride == 2 && a.IW == 17 && a.SG == 72) return gtwo ? wlaunch_ct<true, 2, 17, 72>(a, grid, lds, s, dev) : wlaunch_ct<false, 2, 17, 72>(a, grid, lds, s, dev);
+    }
+  }
   if (gtwo) {
     auto kern = wgrad_mfma_kernel<WM, WN, WAVES_M, WAVES_N, WAVES_K, NBF, SPEC, true>;
     static size_t configured[RCV_MAX_DEVICES];

@@ -175,6 +175,7 @@ class Plan:
         self.input_slots: List[List[tuple]] = []   # per graph input: [(oplist, op index, slot)]
         self.dlogits_slots: List[tuple] = []
         self.logits: Optional[torch.Tensor] = None
+        self.logits_slots: List[tuple] = []   # (fwd op index, slot) of the records that write the logits (inference: a fresh tensor per call)
         self.input_grads: List[Optional[torch.Tensor]] = []
         self.n_head = 0                      # leading ops of fwd that depend on the parameters only (filter repack, eval-mode BN constants)
         self.head_key = None                 # parameter-state key the head was last run for (eval plans)
@@ -466,6 +467,8 @@ class Engine:
                                      % (tuple(w.shape[2:]), Cout, CLS3_PAD))
                 node.out = Value("plain", logits, Cout, src.H, src.W, None, node)
                 plan.logits = logits
+                assert fwd[-1].p[L.RCV_P_OUT] == logits.data_ptr()
+                plan.logits_slots = [(len(fwd) - 1, L.RCV_P_OUT)]
             elif node.op == "add_slice":
                 # out = value(src); out[..., 0:Ca] += value(add)      (LabelProp tail, model.py:565)
                 src, add = ref(d["src"]), ref(d["add"])
@@ -499,6 +502,7 @@ class Engine:
                 fwd.append(op)
                 node.out = Value("plain", out, src.C, src.H, src.W, None, node)
                 plan.logits = out
+                plan.logits_slots = [(len(fwd) - 1, L.RCV_P_OUT)]
             else:
                 raise L.RcvError("unknown graph node '%s'" % node.op)
 
@@ -782,6 +786,7 @@ class Engine:
                     slots[i] = (is_bwd, k + len(head), sl)
         fwd = head + fwd
         plan.n_head = len(head)
+        plan.logits_slots = [(k + len(head), sl) for (k, sl) in plan.logits_slots]
         # backward: the filter gradients (and their reductions) are off the critical path d(loss)/d(activation) chain ->
         # second HIP stream inside rcv_run (measured -4 % step time: their latency-bound phases fill the other kernels' gaps)
         if SIDE_STREAM_WGRAD:
@@ -830,11 +835,19 @@ class Engine:
         the next eval-mode forward re-derives the packed filters and BatchNorm constants instead of reusing its cached head."""
         self.params_dirty = True
 
-    def forward(self, inputs: Sequence[torch.Tensor], training: bool) -> torch.Tensor:
+    def forward(self, inputs: Sequence[torch.Tensor], training: bool, fresh_out: bool = False) -> torch.Tensor:
+        """Runs the forward list.  Returns the engine-owned logits buffer (overwritten by the next forward of this shape) -- or, with
+        ``fresh_out`` on an inference pass, a NEW tensor the last kernel wrote directly (no copy of the result: the reference's modules
+        return fresh tensors, and for one LabelProp frame pair the copy launch was 4 % of the call)."""
         for t in inputs:
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise L.RcvError("engine inputs must be contiguous float32 tensors")
         plan = self._plan_for(inputs, training)
+        out = plan.logits
+        if fresh_out and not training and plan.logits_slots:
+            out = torch.empty_like(plan.logits)
+            for (idx, slot) in plan.logits_slots:
+                plan.fwd.arr[idx].p[slot] = out.data_ptr()
         for k, t in enumerate(inputs):
             for (is_bwd, idx, slot) in plan.input_slots[k]:
                 (plan.bwd if is_bwd else plan.fwd).arr[idx].p[slot] = t.data_ptr()
@@ -859,9 +872,12 @@ class Engine:
                         pl.head_key = None
             else:
                 plan.fwd.run_slice(self.handle, stream, plan.n_head, plan.fwd.n)
+            if out is not plan.logits:       # the records are copied at enqueue: point them back at the engine's own buffer (profile_last re-runs the list)
+                for (idx, slot) in plan.logits_slots:
+                    plan.fwd.arr[idx].p[slot] = plan.logits.data_ptr()
         self._last = (plan, [t for t in inputs])
         self._generation += 1
-        return plan.logits
+        return out
 
     @staticmethod
     def op_work(op) -> tuple:

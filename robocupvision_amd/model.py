@@ -34,7 +34,7 @@ class _EngineFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine: Engine, training: bool, n_inputs: int, *tensors):
         inputs = [t.detach() for t in tensors[:n_inputs]]
-        out = engine.forward(inputs, training)
+        out = engine.forward(inputs, training, fresh_out=not training and not ALIAS_OUTPUTS)
         ctx.engine = engine
         ctx.generation = engine._generation
         ctx.n_inputs = n_inputs
@@ -70,7 +70,8 @@ ALIAS_OUTPUTS = bool(os.environ.get("RCV_ALIAS_OUTPUTS"))
 
 def _run_engine(engine: Engine, training: bool, inputs: List[torch.Tensor]) -> torch.Tensor:
     out = _EngineFunction.apply(engine, training, len(inputs), *inputs, *engine.param_list)
-    return out if ALIAS_OUTPUTS else out.clone()
+    # (an inference pass wrote its result into a fresh tensor already: Engine.forward(fresh_out=True))
+    return out if (ALIAS_OUTPUTS or not training) else out.clone()
 
 
 def _bn_modules(m: nn.Module):

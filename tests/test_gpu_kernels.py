@@ -257,3 +257,47 @@ def test_maxpool_backward_first_maximum_exact(N, H, W, C, affine):
     L.OpList([op]).run(h, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,s,d", [(2, 15, 20, 32, 64, 1, 2), (2, 15, 20, 64, 64, 1, 2), (2, 15, 20, 64, 32, 1, 2), (1, 7, 9, 128, 64, 1, 1),
+                                               (3, 9, 11, 16, 48, 2, 1), (1, 30, 40, 64, 128, 1, 1), (2, 5, 3, 20, 36, 1, 2)])
+@pytest.mark.parametrize("mode_name,flags", [("affine_relu", 0), ("affine", 3), ("plain", 1)])
+def test_tiny_plane_conv_vs_fp64(N, H, W, Cin, Cout, s, d, mode_name, flags):
+    """conv_small.hip (inference on planes of a few hundred pixels: LabelProp's dilated convs for one frame pair, model.py:546-548): one
+    MFMA block per workgroup, K split over its four waves, operands straight from global memory.  Zero padding applies AFTER the load
+    transform (a padded tap contributes 0, not the BatchNorm shift)."""
+    from robocupvision_amd import _lib as L
+    h = L.handle(0)
+    mode = {"plain": L.LOAD_PLAIN, "affine": L.LOAD_AFFINE, "affine_relu": L.LOAD_AFFINE_RELU}[mode_name]
+    gen = torch.Generator().manual_seed(31 + H * W + Cin + Cout)
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    x, c = _rand(gen, N, H, W, Cin), _rand(gen, 5, Cin, scale=0.7)
+    w, b = _rand(gen, Cout, Cin, 3, 3, scale=0.1), _rand(gen, Cout)
+    X = x.double()
+    if mode != L.LOAD_PLAIN:
+        X = X * c[0].double() + c[1].double()
+    if mode == L.LOAD_AFFINE_RELU:
+        X = F.relu(X)
+    use_bias, use_relu = bool(flags & 1), bool(flags & 2)
+    ref = F.conv2d(X.permute(0, 3, 1, 2), w.double(), b.double() if use_bias else None, stride=s, padding=d, dilation=d).permute(0, 2, 3, 1)
+    if use_relu:
+        ref = F.relu(ref)
+    xd, cd, wd, bd = (v.to(DEV) for v in (x, c, w, b))
+    rp, cp = (Cin + 3) // 4 * 4, (Cout + 15) // 16 * 16
+    wp = torch.zeros(9 * rp * cp, device=DEV)
+    job = L.RcvPackJob()
+    job.src, job.dst, job.D0, job.D1 = wd.data_ptr(), wp.data_ptr(), Cout, Cin
+    job.rows_from_d1, job.flip, job.rows_pad, job.cols_pad, job.merged = 1, 0, rp, cp, 0
+    table = torch.frombuffer(bytearray(bytes((L.RcvPackJob * 1)(job))), dtype=torch.uint8).to(DEV)
+    out = torch.full((N, Ho, Wo, Cout), float("nan"), device=DEV)
+    pack = L.make_op(L.OP_PACK, 0, count=1, aux0=9 * rp * cp, p_in=table.data_ptr())
+    conv = L.make_op(L.OP_CONV, (L.F_BIAS if use_bias else 0) | (L.F_RELU if use_relu else 0), n=N, h=H, w=W, cin=Cin, cout=Cout, ho=Ho, wo=Wo,
+                     stride=s, dil=d, inmode=mode, p_in=xd.data_ptr(), p_in_c=cd.data_ptr(), p_w=wp.data_ptr(), p_bias=bd.data_ptr(),
+                     p_out=out.data_ptr())
+    lst = L.OpList([pack, conv])
+    label = lst.labels(h)[1]
+    assert label.startswith("conv_small"), label
+    lst.run(h, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 3e-6, (label, err)
