@@ -1006,7 +1006,9 @@ class Engine:
         """Times the backward list under each schedule (it only overwrites engine buffers: re-running it is harmless) and keeps the fastest."""
         plan.side_decided = True
         capturing = torch.cuda.is_current_stream_capturing()          # (no event synchronisation inside a graph capture)
-        if not SIDE_STREAM_WGRAD or SIDE_STREAM_MODE != "auto" or self.grad_ready_cb is not None or capturing:
+        # (data-parallel runs measure too -- each rank for itself, with plain un-bucketed passes before its first exchange: the three
+        # schedules are bit-identical, so ranks may even settle on different ones)
+        if not SIDE_STREAM_WGRAD or SIDE_STREAM_MODE != "auto" or capturing:
             plan.side_mode = ("all" if SIDE_STREAM_MODE in ("auto", "1") else SIDE_STREAM_MODE) if SIDE_STREAM_WGRAD else "off"
             if plan.side_mode not in self.SIDE_MODES:
                 plan.side_mode = "all"

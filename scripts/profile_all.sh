@@ -4,7 +4,7 @@
 #   configs 2, 3, 5:   kernel trace + stats, FETCH_SIZE, WRITE_SIZE
 #   dominant kernel:   SQ counters of one 128->128 launch (scripts/pmc_op.sh)
 # everything lands in gpurun_out/prof_TAG*/ ; scripts/summarize_profile.py copies the summaries into profiles/
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 # per-kernel numbers are taken with the backward pass on ONE stream: with the filter gradients overlapped on the side stream a
 # kernel's duration includes the time it shares the chip, which is not what bench.py's per-op HIP events report
