@@ -193,6 +193,574 @@ class Plan:
 PLAN_BYTES_BUDGET = 96 << 30      # cached plans beyond this many bytes of engine buffers are dropped, least recently used first
 
 
+class _Lowering:
+    """Lowers one graph for one (input shapes, train|eval) into the two op lists of a Plan: one method per node kind and direction
+    (``fwd_conv`` ... ``bwd_conv``), the shared pieces (filter packing table, BatchNorm bookkeeping records, gradient targets) as small
+    helpers, and ``finish`` for what spans the lists (batched filter-gradient reductions, gradient-ready marks, the pack / eval head).
+    ``eng`` is the Engine that owns the buffers; nothing here runs a kernel."""
+
+    def __init__(self, eng: "Engine", shapes: Sequence[tuple], training: bool):
+        self.eng = eng
+        self.training = training
+        g = eng.graph
+        self.plan = Plan()
+        self.fl = eng.flat
+        self.fwd: List[L.RcvOp] = []
+        self.bwd: List[L.RcvOp] = []
+        self.N = shapes[0][0]
+        # graph inputs
+        self.in_vals: List[Value] = []
+        self.plan.input_slots = [[] for _ in g["inputs"]]
+        for k, (spec, shp) in enumerate(zip(g["inputs"], shapes)):
+            if spec["layout"] == "nchw":
+                _, c, h, w = shp
+                v = Value("nchw", None, c, h, w)
+            else:
+                _, h, w, c = shp
+                v = Value("plain", None, c, h, w)
+                v.needs_grad = bool(spec.get("requires_grad")) and training
+            if shp[0] != self.N:
+                raise L.RcvError("all graph inputs must share the batch size")
+            v.input_index = k
+            self.in_vals.append(v)
+        self.nodes = [_Node(d, i) for i, d in enumerate(g["nodes"])]
+
+        self.jobs: List[L.RcvPackJob] = []          # weight packing table (all layers, one launch per forward)
+        self.pre: List[L.RcvOp] = []                # eval mode: running statistics -> constants, ahead of everything else
+        self.bn_finalize_flags = L.F_TRAINING if training else 0
+        self.batch_at: Dict[int, int] = {}          # index of a folded reduction -> index of the launch that now carries it
+
+    def ref(self, r) -> Value:
+        return self.in_vals[r[1]] if r[0] == "in" else self.nodes[r[1]].out
+
+    def bind_in(self, op_list: List[L.RcvOp], v: Value, slot: int):
+        """Operand `slot` of the op about to be appended reads value v (patched per call for inputs)."""
+        if v.input_index is not None:
+            self.plan.input_slots[v.input_index].append((op_list is self.bwd, len(op_list), slot))
+            return 0
+        return v.buf.data_ptr()
+
+    def add_pack(self, param, D0, D1, rows_from_d1, flip, merged=False, wino=False):
+        rows = D1 if rows_from_d1 else D0
+        cols = D0 if rows_from_d1 else D1
+        rp, cp = _round_up(rows, 4), _round_up(cols * (4 if merged else 1), 16)
+        dst = self.eng._zeros(self.plan, (16 if wino else (4 if merged else 9)) * rp * cp)
+        j = L.RcvPackJob()
+        j.src, j.dst, j.D0, j.D1 = param.data_ptr(), dst.data_ptr(), D0, D1
+        j.rows_from_d1, j.flip, j.rows_pad, j.cols_pad = int(rows_from_d1), int(flip), rp, cp
+        j.merged = 2 if wino else int(merged)
+        self.jobs.append(j)
+        return dst
+
+    def wants_winograd(self, op: L.RcvOp) -> bool:
+        """Ask the library whether this conv record should get the Winograd-transformed filter (and mark the record)."""
+        if WINOGRAD == "off" or not L.op_filter_layout(self.eng.handle, op, WINOGRAD == "force"):
+            return False
+        op.i[L.RCV_I_AUX0] = 2
+        return True
+
+    def use_merged(self, cout: int) -> bool:
+        # narrow transposed convs are HBM bound: one pass writing whole output rows beats four parity passes
+        return cout <= MERGED_TCONV_MAX_COUT
+
+    def bn_tensors(self, node: _Node, Cc: int):
+        node.t["consts"] = self.eng._zeros(self.plan, 5, Cc)
+        node.t["mean"] = self.eng._zeros(self.plan, Cc)
+        node.t["istd"] = self.eng._zeros(self.plan, Cc)
+
+    def emit_bn_forward(self, node: _Node, bn, conv_op: L.RcvOp, Cc: int, Ho: int, Wo: int):
+        """Statistics partials of conv_op -> constants (training) or running stats -> constants (eval)."""
+        if self.training:
+            if self.N * Ho * Wo <= 1:      # same refusal (and text) as torch.nn.functional.batch_norm, which the reference runs
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s" % ((self.N, Cc, Ho, Wo),))
+            conv_op.i[L.RCV_I_STATS] = L.STATS_FWD
+            self.eng._workspace(self.plan, conv_op)
+            self.fwd.append(conv_op)
+            self.fwd.append(L.make_op(L.OP_BN_FINALIZE, self.bn_finalize_flags, n=self.N, ho=Ho, wo=Wo, cout=Cc,
+                                 npart=conv_op.i[L.RCV_I_NPART], f0=BN_MOMENTUM, f1=BN_EPS,
+                                 p_part=conv_op.p[L.RCV_P_PART], p_out=node.t["consts"].data_ptr(),
+                                 p_x0=bn.weight.data_ptr(), p_x1=bn.bias.data_ptr(),
+                                 p_x2=bn.running_mean.data_ptr(), p_x3=bn.running_var.data_ptr(),
+                                 p_x4=node.t["mean"].data_ptr(), p_x5=node.t["istd"].data_ptr()))
+        else:
+            self.pre.append(L.make_op(L.OP_BN_EVAL, 0, cout=Cc, f1=BN_EPS, p_out=node.t["consts"].data_ptr(),
+                                 p_x0=bn.weight.data_ptr(), p_x1=bn.bias.data_ptr(),
+                                 p_x2=bn.running_mean.data_ptr(), p_x3=bn.running_var.data_ptr()))
+            self.fwd.append(conv_op)
+
+    def only_consumer_is_cls1x1(self, idx: int) -> bool:
+        users = [nd for nd in self.nodes if any(nd.d.get(k) == ("node", idx) for k in ("src", "skip", "add"))]
+        return (len(users) == 1 and users[0].op == "cls" and tuple(users[0].d["weight"].shape[2:]) == (1, 1)
+                and 1 <= users[0].d["weight"].shape[0] <= 8)
+
+    def fwd_conv(self, node: _Node):
+        d = node.d
+        src = self.ref(d["src"])
+        w, b, bn = d["weight"], d.get("bias"), d.get("bn")
+        Cout, Cin = w.shape[0], w.shape[1]
+        s, dil = d["stride"], d["dil"]
+        if Cin != src.C:
+            raise L.RcvError("conv node %d: input has %d channels, weight expects %d" % (node.idx, src.C, Cin))
+        Ho, Wo = (src.H - 1) // s + 1, (src.W - 1) // s + 1
+        r = self.eng._alloc(self.plan, self.N, Ho, Wo, Cout)
+        # order: 'relu_bn' = bn(relu(conv)) (Conv, model.py:115-116); 'bn_relu' = relu(bn(conv)) (ConvPoolSimple,
+        # model.py:175; the strided half of ConvPool, model.py:140-142); 'relu' = relu(conv), no BatchNorm (model.py:138-139)
+        order = _conv_order(d)
+        flags = (L.F_BIAS if b is not None else 0) | (L.F_RELU if order != "bn_relu" else 0)
+        op = L.make_op(L.OP_CONV, flags, n=self.N, h=src.H, w=src.W, cin=Cin, cout=Cout, ho=Ho, wo=Wo, stride=s, dil=dil,
+                       inmode=src.load_mode, p_in_c=_ptr(src.consts),
+                       p_bias=_ptr(b), p_out=r.data_ptr())
+        node.t["wp"] = self.add_pack(w, Cout, Cin, True, False, wino=self.wants_winograd(op))
+        op.p[L.RCV_P_W] = node.t["wp"].data_ptr()
+        op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
+        if bn is not None:
+            self.bn_tensors(node, Cout)
+            self.emit_bn_forward(node, bn, op, Cout, Ho, Wo)
+            node.out = Value("affine" if order == "relu_bn" else "affine_relu", r, Cout, Ho, Wo, node.t["consts"], node)
+        else:
+            self.fwd.append(op)
+            node.out = Value("plain", r, Cout, Ho, Wo, None, node)
+
+    def fwd_pool(self, node: _Node):
+        d = node.d
+        src = self.ref(d["src"])
+        if src.H % 2 or src.W % 2:
+            raise L.RcvError("max-pool needs even spatial dims, got %dx%d" % (src.H, src.W))
+        out = self.eng._alloc(self.plan, self.N, src.H // 2, src.W // 2, src.C)
+        op = L.make_op(L.OP_POOL_FWD, 0, n=self.N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
+                       p_in_c=_ptr(src.consts), p_out=out.data_ptr())
+        op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
+        self.fwd.append(op)
+        node.out = Value("plain", out, src.C, src.H // 2, src.W // 2, None, node)
+
+    def fwd_up(self, node: _Node):
+        d = node.d
+        src = self.ref(d["src"])
+        w, b, bn = d["weight"], d.get("bias"), d["bn"]
+        Cin, Cout = w.shape[0], w.shape[1]
+        if Cin != src.C:
+            raise L.RcvError("up node %d: input has %d channels, weight expects %d" % (node.idx, src.C, Cin))
+        Ho, Wo = 2 * src.H, 2 * src.W
+        node.t["wp"] = self.add_pack(w, Cin, Cout, False, False, merged=self.use_merged(Cout))
+        t = self.eng._alloc(self.plan, self.N, Ho, Wo, Cout)
+        self.bn_tensors(node, Cout)
+        op = L.make_op(L.OP_TCONV, (L.F_BIAS if b is not None else 0), n=self.N, h=src.H, w=src.W, cin=Cin, cout=Cout,
+                       ho=Ho, wo=Wo, stride=2, dil=1, aux0=int(self.use_merged(Cout)), inmode=src.load_mode, p_in_c=_ptr(src.consts),
+                       p_w=node.t["wp"].data_ptr(), p_bias=_ptr(b), p_out=t.data_ptr())
+        op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
+        self.emit_bn_forward(node, bn, op, Cout, Ho, Wo)
+        node.t["t"] = t
+        if d.get("skip") is not None:
+            skip = self.ref(d["skip"])
+            if (skip.C, skip.H, skip.W) != (Cout, Ho, Wo):
+                raise L.RcvError("up node %d: skip tensor %s does not match output %s" %
+                                 (node.idx, (skip.C, skip.H, skip.W), (Cout, Ho, Wo)))
+            concat = bool(d.get("concat"))      # v2: torch.cat([layer(up), skip], 1) instead of the add (model.py:507)
+            if not concat and FUSE_UP_INTO_CLS and Cout == 8 and skip.input_index is None and self.only_consumer_is_cls1x1(node.idx):
+                # the 1x1 classifier forms relu(bn(t)) + bn(skip) itself (RCV_F_FUSED_UP): no RCV_OP_COMBINE, `up` never exists
+                node.out = Value("fused_up", None, Cout, Ho, Wo, node.t["consts"], node)
+                node.out.fused = (t, skip)
+                return
+            Cup = 2 * Cout if concat else Cout
+            up = self.eng._alloc(self.plan, self.N, Ho, Wo, Cup)
+            cop = L.make_op(L.OP_COMBINE, L.F_CONCAT if concat else 0, n=self.N, h=Ho, w=Wo, cout=Cout, inmode2=skip.load_mode,
+                            p_in=t.data_ptr(), p_in_c=node.t["consts"].data_ptr(), p_in2_c=_ptr(skip.consts), p_out=up.data_ptr())
+            cop.p[L.RCV_P_IN2] = self.bind_in(self.fwd, skip, L.RCV_P_IN2) or None
+            self.fwd.append(cop)
+            node.out = Value("plain", up, Cup, Ho, Wo, None, node)
+        else:
+            node.out = Value("affine_relu", t, Cout, Ho, Wo, node.t["consts"], node)
+
+    def fwd_cls(self, node: _Node):
+        d = node.d
+        src = self.ref(d["src"])
+        w, b = d["weight"], d.get("bias")
+        Cout, Cin = w.shape[0], w.shape[1]
+        if src.kind not in ("plain", "fused_up"):
+            raise L.RcvError("classifier input must be a materialised tensor")
+        if Cin != src.C:
+            raise L.RcvError("classifier: input has %d channels, weight expects %d" % (src.C, Cin))
+        logits = self.eng._alloc(self.plan, self.N, Cout, src.H, src.W)
+        if tuple(w.shape[2:]) == (1, 1) and src.kind == "fused_up":
+            tt, skip = src.fused
+            self.fwd.append(L.make_op(L.OP_CLS_FWD, L.F_FUSED_UP, n=self.N, h=src.H, w=src.W, cin=Cin, cout=Cout, aux0=skip.load_mode,
+                                 aux1=getattr(src, "fused_rch", 0),
+                                 p_in=tt.data_ptr(), p_in_c=src.consts.data_ptr(), p_x3=skip.buf.data_ptr(), p_x4=_ptr(skip.consts),
+                                 p_w=w.data_ptr(), p_bias=_ptr(b), p_out=logits.data_ptr()))
+        elif tuple(w.shape[2:]) == (1, 1):
+            op = L.make_op(L.OP_CLS_FWD, 0, n=self.N, h=src.H, w=src.W, cin=Cin, cout=Cout, p_w=w.data_ptr(), p_bias=_ptr(b),
+                           p_out=logits.data_ptr())
+            op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
+            self.fwd.append(op)
+        elif tuple(w.shape[2:]) == (3, 3) and Cout <= CLS3_PAD:
+            # v2 (classSize=3): the MFMA conv with the class channels padded to 8, NHWC; then bias + NHWC -> NCHW
+            node.t["wp"] = self.add_pack(w, Cout, Cin, True, False)
+            node.t["z"] = self.eng._alloc(self.plan, self.N, src.H, src.W, CLS3_PAD)
+            op = L.make_op(L.OP_CONV, 0, n=self.N, h=src.H, w=src.W, cin=Cin, cout=CLS3_PAD, ho=src.H, wo=src.W, stride=1, dil=1,
+                           inmode=src.load_mode, p_w=node.t["wp"].data_ptr(), p_out=node.t["z"].data_ptr())
+            op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
+            self.fwd.append(op)
+            self.fwd.append(L.make_op(L.OP_NHWC_TO_NCHW, 0, n=self.N, h=src.H, w=src.W, cin=CLS3_PAD, cout=Cout, p_in=node.t["z"].data_ptr(),
+                                 p_bias=_ptr(b), p_out=logits.data_ptr()))
+        else:
+            raise L.RcvError("classifier kernels %s with %d classes are not built (1x1, or 3x3 with <= %d classes)"
+                             % (tuple(w.shape[2:]), Cout, CLS3_PAD))
+        node.out = Value("plain", logits, Cout, src.H, src.W, None, node)
+        self.plan.logits = logits
+        assert self.fwd[-1].p[L.RCV_P_OUT] == logits.data_ptr()
+        self.plan.logits_slots = [(len(self.fwd) - 1, L.RCV_P_OUT)]
+
+    def fwd_add_slice(self, node: _Node):
+        d = node.d
+        # out = value(src); out[..., 0:Ca] += value(add)      (LabelProp tail, model.py:565)
+        src, add = self.ref(d["src"]), self.ref(d["add"])
+        if (add.H, add.W) != (src.H, src.W) or add.C > src.C:
+            raise L.RcvError("add_slice: operand shapes do not match")
+        if (FUSE_UP_INTO_CLS and not self.training and src.kind == "affine_relu" and src.C == 16 and add.C % 4 == 0 and add.buf is not None
+                and add.input_index is None and src.input_index is None and add.kind in ("plain", "affine", "affine_relu")
+                and self.only_consumer_is_cls1x1(node.idx)):
+            # LabelProp's tail (model.py:563-567): the 1x1 classifier forms relu(bn(t)) and adds the skip to its first add.C input
+            # channels itself (RCV_F_FUSED_UP with i[RCV_I_AUX1] = add.C): no RCV_OP_MATERIALIZE / RCV_OP_ADD_SLICE passes
+            node.out = Value("fused_up", None, src.C, src.H, src.W, src.consts, node)
+            node.out.fused = (src.buf, add)
+            node.out.fused_rch = add.C
+            return
+        out = self.eng._alloc(self.plan, self.N, src.H, src.W, src.C)
+        op = L.make_op(L.OP_MATERIALIZE, 0, n=self.N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
+                       p_in_c=_ptr(src.consts), p_out=out.data_ptr())
+        op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
+        self.fwd.append(op)
+        op2 = L.make_op(L.OP_ADD_SLICE, 0, n=self.N, h=src.H, w=src.W, cin=add.C, cout=src.C, inmode=add.load_mode,
+                        p_in_c=_ptr(add.consts), p_out=out.data_ptr())
+        op2.p[L.RCV_P_IN] = self.bind_in(self.fwd, add, L.RCV_P_IN) or None
+        self.fwd.append(op2)
+        node.out = Value("plain", out, src.C, src.H, src.W, None, node)
+
+    def fwd_mat(self, node: _Node):
+        d = node.d
+        src = self.ref(d["src"])
+        out = self.eng._alloc(self.plan, self.N, src.H, src.W, src.C)
+        op = L.make_op(L.OP_MATERIALIZE, 0, n=self.N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
+                       p_in_c=_ptr(src.consts), p_out=out.data_ptr())
+        op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
+        self.fwd.append(op)
+        node.out = Value("plain", out, src.C, src.H, src.W, None, node)
+        self.plan.logits = out
+        self.plan.logits_slots = [(len(self.fwd) - 1, L.RCV_P_OUT)]
+
+    def grad_target(self, v: Value, writer_op: L.RcvOp, Ho: int, Wo: int):
+        """Configure writer_op (a dgrad-like op) to produce d loss / d v with the epilogue v's producer needs."""
+        v.grad = self.eng._alloc(self.plan, self.N, v.H, v.W, v.C)
+        writer_op.p[L.RCV_P_OUT] = v.grad.data_ptr()
+        if v.skip_grad is not None:
+            writer_op.flags |= L.F_RESID
+            writer_op.p[L.RCV_P_RESID] = v.skip_grad.data_ptr()
+        prod = v.producer
+        if prod is None:
+            self.plan.input_grads[v.input_index] = v.grad
+            writer_op.i[L.RCV_I_STATS] = L.STATS_NONE
+        elif prod.op == "conv" and prod.d.get("bn") is not None:
+            writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_ENC if _conv_order(prod.d) == "relu_bn" else L.STATS_BWD_DEC
+            writer_op.p[L.RCV_P_EPI_AUX] = v.buf.data_ptr()
+            writer_op.p[L.RCV_P_EPI_C] = prod.t["consts"].data_ptr()     # row 2 = batch mean
+        elif prod.op == "up" and not prod.d.get("concat"):
+            writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_DEC
+            writer_op.p[L.RCV_P_EPI_AUX] = prod.t["t"].data_ptr()
+            writer_op.p[L.RCV_P_EPI_C] = prod.t["consts"].data_ptr()
+        else:
+            writer_op.i[L.RCV_I_STATS] = L.STATS_NONE
+        self.eng._workspace(self.plan, writer_op)
+        if writer_op.i[L.RCV_I_STATS] != L.STATS_NONE:
+            prod.t["bwd_part"] = (writer_op.p[L.RCV_P_PART], writer_op.i[L.RCV_I_NPART])
+
+    def emit_bn_backward(self, node: _Node, bn, Cc: int, Ho: int, Wo: int):
+        part_ptr, n_part = node.t["bwd_part"]
+        node.t["bconsts"] = self.eng._zeros(self.plan, 5, Cc)
+        self.bwd.append(L.make_op(L.OP_BN_BWD, 0, n=self.N, ho=Ho, wo=Wo, cout=Cc, npart=n_part, p_part=part_ptr,
+                             p_out=node.t["bconsts"].data_ptr(), p_in_c=node.t["consts"].data_ptr(),
+                             p_x0=bn.weight.data_ptr(), p_x1=self.fl.grad_ptr(bn.weight), p_x2=self.fl.grad_ptr(bn.bias),
+                             p_x4=node.t["mean"].data_ptr(), p_x5=node.t["istd"].data_ptr()))
+
+    def node_params(self, nd):
+        ps = [nd.d.get("weight"), nd.d.get("bias")]
+        bn_ = nd.d.get("bn")
+        if bn_ is not None:
+            ps += [bn_.weight, bn_.bias]
+        return [q for q in ps if q is not None]
+
+    def bwd_cls(self, node: _Node):
+        d = node.d
+        src = self.ref(d["src"])
+        w, b = d["weight"], d.get("bias")
+        Cout, Cin = w.shape[0], w.shape[1]
+        if "z" in node.t:      # 3x3 classifier: NCHW dlogits -> padded NHWC, then the ordinary filter / data gradients
+            if src.input_index is not None:
+                raise L.RcvError("the 3x3 classifier cannot read a graph input directly")
+            g8 = self.eng._alloc(self.plan, self.N, src.H, src.W, CLS3_PAD)
+            self.plan.dlogits_slots.append((len(self.bwd), L.RCV_P_IN))
+            self.bwd.append(L.make_op(L.OP_NCHW_TO_NHWC, 0, n=self.N, h=src.H, w=src.W, cin=Cout, cout=CLS3_PAD, p_out=g8.data_ptr()))
+            wop = L.make_op(L.OP_WGRAD, (L.F_BIAS if b is not None else 0), n=self.N, h=src.H, w=src.W, cin=Cin, ho=src.H, wo=src.W,
+                            cout=CLS3_PAD, stride=1, dil=1, inmode=src.load_mode, inmode2=L.LOAD_PLAIN,
+                            p_in=src.buf.data_ptr(), p_in_c=_ptr(src.consts), p_in2=g8.data_ptr())
+            self.eng._workspace(self.plan, wop)
+            self.bwd.append(wop)
+            self.bwd.append(L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cin, cout=Cout, nsplit=wop.i[L.RCV_I_NSPLIT],
+                                 p_part=wop.p[L.RCV_P_PART], p_out=self.fl.grad_ptr(w),
+                                 p_bias=(self.fl.grad_ptr(b) if b is not None else 0)))
+            if src.needs_grad:
+                node.t["wd"] = self.add_pack(w, Cout, Cin, False, True)
+                dop = L.make_op(L.OP_CONV, 0, n=self.N, h=src.H, w=src.W, cin=CLS3_PAD, cout=Cin, ho=src.H, wo=src.W, stride=1, dil=1,
+                                inmode=L.LOAD_PLAIN, p_in=g8.data_ptr(), p_w=node.t["wd"].data_ptr())
+                self.grad_target(src, dop, src.H, src.W)
+                self.bwd.append(dop)
+            return
+        op = L.make_op(L.OP_CLS_BWD, 0, n=self.N, h=src.H, w=src.W, cin=Cin, cout=Cout, p_in=src.buf.data_ptr() if src.buf is not None else 0,
+                       p_w=w.data_ptr(), p_x1=self.fl.grad_ptr(w), p_x2=(self.fl.grad_ptr(b) if b is not None else 0))
+        if src.kind == "fused_up":
+            _tt, skip = src.fused
+            op.flags |= L.F_FUSED_UP
+            op.i[L.RCV_I_AUX0] = skip.load_mode
+            op.p[L.RCV_P_X3] = skip.buf.data_ptr()
+            op.p[L.RCV_P_X4] = _ptr(skip.consts) or None
+        if src.input_index is not None:
+            self.plan.input_slots[src.input_index].append((True, len(self.bwd), L.RCV_P_IN))
+        self.plan.dlogits_slots.append((len(self.bwd), L.RCV_P_IN2))
+        self.grad_target(src, op, src.H, src.W)
+        self.bwd.append(op)
+
+    def bwd_mat(self, node: _Node):
+        d = node.d
+        # the gradient of the materialised output arrives from outside: copy + BN-backward sums
+        src = self.ref(d["src"])
+        op = L.make_op(L.OP_BWD_STATS, 0, n=self.N, h=src.H, w=src.W, cout=src.C)
+        self.plan.dlogits_slots.append((len(self.bwd), L.RCV_P_IN))
+        self.grad_target(src, op, src.H, src.W)
+        if op.i[L.RCV_I_STATS] == L.STATS_NONE:
+            raise L.RcvError("a materialised output must follow a conv or up block")
+        self.bwd.append(op)
+
+    def bwd_up(self, node: _Node):
+        d = node.d
+        out, src = node.out, self.ref(d["src"])
+        w, b, bn = d["weight"], d.get("bias"), d["bn"]
+        Cin, Cout = w.shape[0], w.shape[1]
+        if out.grad is None:
+            raise L.RcvError("up node %d has no consumer that produces its gradient" % node.idx)
+        gout = out.grad
+        if d.get("skip") is not None and d.get("concat"):
+            # gradient of the concatenation: channels [0,C) belong to this block (copied out together with its
+            # BatchNorm-backward sums), channels [C,2C) to the skip tensor
+            gout = self.eng._alloc(self.plan, self.N, out.H, out.W, Cout)
+            sop = L.make_op(L.OP_BWD_STATS, 0, n=self.N, h=out.H, w=out.W, cin=2 * Cout, cout=Cout, aux0=0, stats=L.STATS_BWD_DEC,
+                            p_in=out.grad.data_ptr(), p_epi_aux=node.t["t"].data_ptr(), p_epi_c=node.t["consts"].data_ptr(),
+                            p_out=gout.data_ptr())
+            self.eng._workspace(self.plan, sop)
+            node.t["bwd_part"] = (sop.p[L.RCV_P_PART], sop.i[L.RCV_I_NPART])
+            self.bwd.append(sop)
+            gskip = self.eng._alloc(self.plan, self.N, out.H, out.W, Cout)
+            self.bwd.append(L.make_op(L.OP_BWD_STATS, 0, n=self.N, h=out.H, w=out.W, cin=2 * Cout, cout=Cout, aux0=Cout, stats=L.STATS_NONE,
+                                 p_in=out.grad.data_ptr(), p_out=gskip.data_ptr()))
+            self.ref(d["skip"]).skip_grad = gskip
+        elif d.get("skip") is not None:
+            self.ref(d["skip"]).skip_grad = out.grad        # d up / d skip = identity
+        self.emit_bn_backward(node, bn, Cout, out.H, out.W)
+        # filter gradient: G = dt (2x plane), P = layer input
+        wop = L.make_op(L.OP_WGRAD, 0, n=self.N, h=out.H, w=out.W, cin=Cout, ho=src.H, wo=src.W, cout=Cin, stride=2, dil=1,
+                        inmode=L.LOAD_GRAD_DEC, inmode2=src.load_mode, p_in=gout.data_ptr(),
+                        p_in_aux=node.t["t"].data_ptr(), p_in_c=node.t["bconsts"].data_ptr(),
+                        p_in2_c=_ptr(src.consts))
+        wop.p[L.RCV_P_IN2] = (src.buf.data_ptr() if src.buf is not None else None)
+        if src.input_index is not None:
+            self.plan.input_slots[src.input_index].append((True, len(self.bwd), L.RCV_P_IN2))
+        self.eng._workspace(self.plan, wop)
+        self.bwd.append(wop)
+        self.bwd.append(L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cout, cout=Cin, nsplit=wop.i[L.RCV_I_NSPLIT],
+                             p_part=wop.p[L.RCV_P_PART], p_out=self.fl.grad_ptr(w)))
+        if b is not None:   # bias ahead of a BatchNorm: gradient is identically zero (DESIGN.md 4.3)
+            self.bwd.append(L.make_op(L.OP_MEMSET, 0, count=b.numel(), p_out=self.fl.grad_ptr(b)))
+        if src.needs_grad:
+            node.t["wd"] = self.add_pack(w, Cin, Cout, True, False)
+            dop = L.make_op(L.OP_CONV, 0, n=self.N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=2, dil=1,
+                            inmode=L.LOAD_GRAD_DEC, p_in=gout.data_ptr(), p_in_aux=node.t["t"].data_ptr(),
+                            p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
+            self.grad_target(src, dop, src.H, src.W)
+            self.bwd.append(dop)
+
+    def bwd_pool(self, node: _Node):
+        d = node.d
+        out, src = node.out, self.ref(d["src"])
+        if out.grad is None:
+            raise L.RcvError("pool node %d has no gradient producer" % node.idx)
+        if src.needs_grad:
+            pop = L.make_op(L.OP_POOL_BWD, 0, n=self.N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
+                            p_in=out.grad.data_ptr(), p_in_c=_ptr(src.consts))
+            self.grad_target(src, pop, src.H, src.W)
+            # pool backward recomputes the arg-max from the producer's r; for non-BN producers use the tensor itself
+            pop.p[L.RCV_P_EPI_AUX] = src.buf.data_ptr() if src.buf is not None else None
+            if src.input_index is not None:
+                self.plan.input_slots[src.input_index].append((True, len(self.bwd), L.RCV_P_EPI_AUX))
+            if src.producer is not None and src.producer.op == "up":
+                raise L.RcvError("max-pool directly after a decoder block is not supported")
+            self.bwd.append(pop)
+
+    def bwd_conv(self, node: _Node):
+        d = node.d
+        out, src = node.out, self.ref(d["src"])
+        w, b, bn = d["weight"], d.get("bias"), d.get("bn")
+        Cout, Cin = w.shape[0], w.shape[1]
+        s, dil = d["stride"], d["dil"]
+        order = _conv_order(d)
+        if out.grad is None:
+            raise L.RcvError("conv node %d has no gradient producer" % node.idx)
+        if bn is not None:
+            self.emit_bn_backward(node, bn, Cout, out.H, out.W)
+        else:       # relu(conv): the gradient load is the ReLU mask alone, v = r > 0 ? 1*g + 0 + 0*r : 0
+            ones = self.eng._zeros(self.plan, 5, Cout)
+            ones[0].fill_(1.0)
+            node.t["bconsts"] = ones
+        gmode = L.LOAD_GRAD_DEC if order == "bn_relu" else L.LOAD_GRAD_ENC
+        bias_grad = b is not None and order != "bn_relu"
+        wop = L.make_op(L.OP_WGRAD, (L.F_BIAS if bias_grad else 0), n=self.N, h=src.H, w=src.W, cin=Cin, ho=out.H, wo=out.W,
+                        cout=Cout, stride=s, dil=dil, inmode=src.load_mode, inmode2=gmode,
+                        p_in_c=_ptr(src.consts), p_in2=out.grad.data_ptr(), p_in2_aux=out.buf.data_ptr(),
+                        p_in2_c=node.t["bconsts"].data_ptr())
+        wop.p[L.RCV_P_IN] = (src.buf.data_ptr() if src.buf is not None else None)
+        if src.input_index is not None:
+            self.plan.input_slots[src.input_index].append((True, len(self.bwd), L.RCV_P_IN))
+        self.eng._workspace(self.plan, wop)
+        self.bwd.append(wop)
+        self.bwd.append(L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cin, cout=Cout, nsplit=wop.i[L.RCV_I_NSPLIT],
+                             p_part=wop.p[L.RCV_P_PART], p_out=self.fl.grad_ptr(w),
+                             p_bias=(self.fl.grad_ptr(b) if bias_grad else 0)))
+        if b is not None and not bias_grad:   # bias ahead of a BatchNorm: gradient is identically zero
+            self.bwd.append(L.make_op(L.OP_MEMSET, 0, count=b.numel(), p_out=self.fl.grad_ptr(b)))
+        if src.needs_grad:
+            if s == 1:
+                dop = L.make_op(L.OP_CONV, 0, n=self.N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=1, dil=dil,
+                                inmode=gmode, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
+                                p_in_c=node.t["bconsts"].data_ptr())
+                node.t["wd"] = self.add_pack(w, Cout, Cin, False, True, wino=self.wants_winograd(dop))
+                dop.p[L.RCV_P_W] = node.t["wd"].data_ptr()
+            else:
+                if src.H != 2 * out.H or src.W != 2 * out.W:
+                    raise L.RcvError("stride-2 conv backward needs even input dims (got %dx%d)" % (src.H, src.W))
+                node.t["wd"] = self.add_pack(w, Cout, Cin, False, False, merged=self.use_merged(Cin))
+                dop = L.make_op(L.OP_TCONV, 0, n=self.N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=2, dil=1,
+                                aux0=int(self.use_merged(Cin)),
+                                inmode=gmode, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
+                                p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
+            self.grad_target(src, dop, src.H, src.W)
+            self.bwd.append(dop)
+
+    def run(self) -> Plan:
+        for node in self.nodes:
+            lower = getattr(self, "fwd_" + node.op, None)
+            if lower is None:
+                raise L.RcvError("unknown graph node '%s'" % node.op)
+            lower(node)
+        self.plan.input_grads = [None] * len(self.in_vals)
+        if self.training:
+            # which values need a gradient: everything produced by a node, plus flagged inputs
+            for node in self.nodes:
+                if node.op == "add_slice":
+                    raise L.RcvError("this graph is inference only (add_slice has no backward); call .eval()")
+                if node.op not in ("cls", "mat"):
+                    node.out.needs_grad = True
+
+            for node in reversed(self.nodes):
+                self.plan.bwd_marks.append([len(self.bwd), node])      # patched to (op count after this node, min flat offset) in finish()
+                getattr(self, "bwd_" + node.op)(node)
+        return self.finish()
+
+    def finish(self) -> Plan:
+        plan, fwd, bwd, fl, training = self.plan, self.fwd, self.bwd, self.fl, self.training
+        # ---- batched filter-gradient reductions: the records keep their positions (every index into the list stays valid); all but
+        # the last reduction of a group become RCV_OP_NOP, the last one becomes the table-driven launch of the whole group ----
+        plan.reduce_outputs = {}               # index of a batched launch -> [(gradient pointer it writes, zero-fill?)] (schedule tests)
+        if training and REDUCE_BATCH > 1:
+            idxs = [k for k, op in enumerate(bwd) if op.kind == L.OP_WGRAD_REDUCE]
+            for g0 in range(0, len(idxs), REDUCE_BATCH):
+                grp = idxs[g0:g0 + REDUCE_BATCH]
+                if len(grp) < 2:
+                    continue
+                # the bias-gradient memsets between the group's first and last reduction ride along as zero-fill jobs
+                grp = sorted(grp + [k for k in range(grp[0], grp[-1]) if bwd[k].kind == L.OP_MEMSET])
+                rjobs, first, kib, outs = [], 0, 0.0, []
+                for k in grp:
+                    op = bwd[k]
+                    if op.kind == L.OP_MEMSET:
+                        cnt = op.i[L.RCV_I_COUNT]
+                        rjobs.append(L.RcvReduceJob(part=None, dw=None, db=op.p[L.RCV_P_OUT], nsplit=0, CB=cnt, CA=0, first_block=first))
+                        first += -(-cnt // 256)
+                        outs.append((op.p[L.RCV_P_OUT], True))
+                        continue
+                    ca, cb, ns = op.i[L.RCV_I_CIN], op.i[L.RCV_I_COUT], op.i[L.RCV_I_NSPLIT]
+                    cap, cbp = (4 if ca <= 4 else _round_up(ca, 16)), _round_up(cb, 16)
+                    db = op.p[L.RCV_P_BIAS] or None
+                    rjobs.append(L.RcvReduceJob(part=op.p[L.RCV_P_PART], dw=op.p[L.RCV_P_OUT], db=db, nsplit=ns, CB=cb, CA=ca, first_block=first))
+                    first += -(-(9 * cbp * cap + (cbp if db else 0)) // 64)
+                    kib += self.eng.op_work(op)[1] / 1024.0
+                    outs += [(q, False) for q in (op.p[L.RCV_P_OUT], db) if q]
+                table = (L.RcvReduceJob * len(rjobs))(*rjobs)
+                dev_table = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.eng.device)
+                plan.keep.append(dev_table)
+                for k in grp[:-1]:
+                    bwd[k] = L.make_op(L.OP_NOP, 0)
+                    self.batch_at[k] = grp[-1]
+                bwd[grp[-1]] = L.make_op(L.OP_WGRAD_REDUCE_BATCH, 0, count=len(rjobs), npart=first, aux0=int(kib), p_in=dev_table.data_ptr())
+                self.batch_at[grp[-1]] = grp[-1]
+                plan.reduce_outputs[grp[-1]] = outs
+
+        # gradient-ready marks: after bwd ops [0:end) every parameter at flat offset >= lo is final (parameters are laid
+        # out in forward order and backward visits the nodes in reverse, so the finished region is a growing suffix)
+        marks, lo, prev_end = [], fl.numel, 0
+        for k, (start, node) in enumerate(plan.bwd_marks):
+            end = plan.bwd_marks[k + 1][0] if k + 1 < len(plan.bwd_marks) else len(bwd)
+            for q in range(start, end):            # a node whose reduction was folded into a later launch is final only behind that launch
+                if q in self.batch_at:
+                    end = max(end, self.batch_at[q] + 1)
+            end = prev_end = max(end, prev_end)
+            offs = [fl.offsets[fl.index(q)] for q in self.node_params(node)] if training else []
+            if offs:
+                lo = min(lo, min(offs))
+            if end > 0 and (not marks or marks[-1][0] != end):
+                marks.append((end, lo))
+            elif marks:
+                marks[-1] = (end, min(marks[-1][1], lo))
+        plan.bwd_marks = marks if training else []
+
+        # ---- the pack launch goes first in the forward list ----
+        head = list(self.pre)
+        if self.jobs:        # (a graph without 3x3 filters -- a lone 1x1 classifier -- packs nothing)
+            table = (L.RcvPackJob * len(self.jobs))(*self.jobs)
+            host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
+            dev_table = host.to(self.eng.device)
+            plan.keep.append(dev_table)
+            assert C.sizeof(table) == dev_table.numel()
+            max_elems = max((4 if j.merged == 1 else 9) * j.rows_pad * j.cols_pad for j in self.jobs)
+            head = [L.make_op(L.OP_PACK, 0, count=len(self.jobs), aux0=max_elems, p_in=dev_table.data_ptr())] + head
+        for slots in plan.input_slots:
+            for i, (is_bwd, k, sl) in enumerate(slots):
+                if not is_bwd:
+                    slots[i] = (is_bwd, k + len(head), sl)
+        fwd = head + fwd
+        plan.n_head = len(head)
+        plan.logits_slots = [(k + len(head), sl) for (k, sl) in plan.logits_slots]
+        # backward: the filter gradients (and their reductions) are off the critical path d(loss)/d(activation) chain ->
+        # second HIP stream inside rcv_run (measured -4 % step time: their latency-bound phases fill the other kernels' gaps)
+        if SIDE_STREAM_WGRAD:
+            for op in bwd:
+                if op.kind in (L.OP_WGRAD, L.OP_WGRAD_REDUCE, L.OP_WGRAD_REDUCE_BATCH, L.OP_MEMSET):
+                    op.flags |= L.F_SIDE_STREAM
+        plan.fwd = L.OpList(fwd)
+        plan.bwd = L.OpList(bwd)
+        # plan-time validation: the library answers a query for a record exactly when it would launch it (every shape refusal sits in
+        # front of the query return), so an unsupported layer raises HERE with the library's message, not at the first backward
+        plan.fwd.labels(self.eng.handle)
+        plan.bwd.labels(self.eng.handle)
+        return plan
+
+
 class Engine:
     def __init__(self, graph: dict, params: Sequence[torch.nn.Parameter], bn_modules: Sequence[torch.nn.Module], dry_run: bool = False):
         # dry_run: lower graphs to op lists on whatever device the parameters are on (CPU included) through a planning-only
@@ -264,542 +832,7 @@ class Engine:
 
     # ------------------------------------------------------------------ plan construction
     def _build(self, shapes: Sequence[tuple], training: bool) -> Plan:
-        g = self.graph
-        plan = Plan()
-        fl = self.flat
-        fwd: List[L.RcvOp] = []
-        bwd: List[L.RcvOp] = []
-        N = shapes[0][0]
-        # graph inputs
-        in_vals: List[Value] = []
-        plan.input_slots = [[] for _ in g["inputs"]]
-        for k, (spec, shp) in enumerate(zip(g["inputs"], shapes)):
-            if spec["layout"] == "nchw":
-                _, c, h, w = shp
-                v = Value("nchw", None, c, h, w)
-            else:
-                _, h, w, c = shp
-                v = Value("plain", None, c, h, w)
-                v.needs_grad = bool(spec.get("requires_grad")) and training
-            if shp[0] != N:
-                raise L.RcvError("all graph inputs must share the batch size")
-            v.input_index = k
-            in_vals.append(v)
-        nodes = [_Node(d, i) for i, d in enumerate(g["nodes"])]
-
-        def ref(r) -> Value:
-            return in_vals[r[1]] if r[0] == "in" else nodes[r[1]].out
-
-        def bind_in(op_list: List[L.RcvOp], v: Value, slot: int):
-            """Operand `slot` of the op about to be appended reads value v (patched per call for inputs)."""
-            if v.input_index is not None:
-                plan.input_slots[v.input_index].append((op_list is bwd, len(op_list), slot))
-                return 0
-            return v.buf.data_ptr()
-
-        # ---- weight packing table (all layers, one launch per forward) ----
-        jobs: List[L.RcvPackJob] = []
-
-        def add_pack(param, D0, D1, rows_from_d1, flip, merged=False, wino=False):
-            rows = D1 if rows_from_d1 else D0
-            cols = D0 if rows_from_d1 else D1
-            rp, cp = _round_up(rows, 4), _round_up(cols * (4 if merged else 1), 16)
-            dst = self._zeros(plan, (16 if wino else (4 if merged else 9)) * rp * cp)
-            j = L.RcvPackJob()
-            j.src, j.dst, j.D0, j.D1 = param.data_ptr(), dst.data_ptr(), D0, D1
-            j.rows_from_d1, j.flip, j.rows_pad, j.cols_pad = int(rows_from_d1), int(flip), rp, cp
-            j.merged = 2 if wino else int(merged)
-            jobs.append(j)
-            return dst
-
-        def wants_winograd(op: L.RcvOp) -> bool:
-            """Ask the library whether this conv record should get the Winograd-transformed filter (and mark the record)."""
-            if WINOGRAD == "off" or not L.op_filter_layout(self.handle, op, WINOGRAD == "force"):
-                return False
-            op.i[L.RCV_I_AUX0] = 2
-            return True
-
-        def use_merged(cout: int) -> bool:
-            # narrow transposed convs are HBM bound: one pass writing whole output rows beats four parity passes
-            return cout <= MERGED_TCONV_MAX_COUT
-
-        bn_finalize_flags = L.F_TRAINING if training else 0
-
-        def bn_tensors(node: _Node, Cc: int):
-            node.t["consts"] = self._zeros(plan, 5, Cc)
-            node.t["mean"] = self._zeros(plan, Cc)
-            node.t["istd"] = self._zeros(plan, Cc)
-
-        pre: List[L.RcvOp] = []      # eval mode: running statistics -> constants, ahead of everything else
-
-        def emit_bn_forward(node: _Node, bn, conv_op: L.RcvOp, Cc: int, Ho: int, Wo: int):
-            """Statistics partials of conv_op -> constants (training) or running stats -> constants (eval)."""
-            if training:
-                if N * Ho * Wo <= 1:      # same refusal (and text) as torch.nn.functional.batch_norm, which the reference runs
-                    raise ValueError("Expected more than 1 value per channel when training, got input size %s" % ((N, Cc, Ho, Wo),))
-                conv_op.i[L.RCV_I_STATS] = L.STATS_FWD
-                self._workspace(plan, conv_op)
-                fwd.append(conv_op)
-                fwd.append(L.make_op(L.OP_BN_FINALIZE, bn_finalize_flags, n=N, ho=Ho, wo=Wo, cout=Cc,
-                                     npart=conv_op.i[L.RCV_I_NPART], f0=BN_MOMENTUM, f1=BN_EPS,
-                                     p_part=conv_op.p[L.RCV_P_PART], p_out=node.t["consts"].data_ptr(),
-                                     p_x0=bn.weight.data_ptr(), p_x1=bn.bias.data_ptr(),
-                                     p_x2=bn.running_mean.data_ptr(), p_x3=bn.running_var.data_ptr(),
-                                     p_x4=node.t["mean"].data_ptr(), p_x5=node.t["istd"].data_ptr()))
-            else:
-                pre.append(L.make_op(L.OP_BN_EVAL, 0, cout=Cc, f1=BN_EPS, p_out=node.t["consts"].data_ptr(),
-                                     p_x0=bn.weight.data_ptr(), p_x1=bn.bias.data_ptr(),
-                                     p_x2=bn.running_mean.data_ptr(), p_x3=bn.running_var.data_ptr()))
-                fwd.append(conv_op)
-
-        def only_consumer_is_cls1x1(idx: int) -> bool:
-            users = [nd for nd in nodes if any(nd.d.get(k) == ("node", idx) for k in ("src", "skip", "add"))]
-            return (len(users) == 1 and users[0].op == "cls" and tuple(users[0].d["weight"].shape[2:]) == (1, 1)
-                    and 1 <= users[0].d["weight"].shape[0] <= 8)
-
-        # =============================== forward ===============================
-        for node in nodes:
-            d = node.d
-            if node.op == "conv":
-                src = ref(d["src"])
-                w, b, bn = d["weight"], d.get("bias"), d.get("bn")
-                Cout, Cin = w.shape[0], w.shape[1]
-                s, dil = d["stride"], d["dil"]
-                if Cin != src.C:
-                    raise L.RcvError("conv node %d: input has %d channels, weight expects %d" % (node.idx, src.C, Cin))
-                Ho, Wo = (src.H - 1) // s + 1, (src.W - 1) // s + 1
-                r = self._alloc(plan, N, Ho, Wo, Cout)
-                # order: 'relu_bn' = bn(relu(conv)) (Conv, model.py:115-116); 'bn_relu' = relu(bn(conv)) (ConvPoolSimple,
-                # model.py:175; the strided half of ConvPool, model.py:140-142); 'relu' = relu(conv), no BatchNorm (model.py:138-139)
-                order = _conv_order(d)
-                flags = (L.F_BIAS if b is not None else 0) | (L.F_RELU if order != "bn_relu" else 0)
-                op = L.make_op(L.OP_CONV, flags, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, ho=Ho, wo=Wo, stride=s, dil=dil,
-                               inmode=src.load_mode, p_in_c=_ptr(src.consts),
-                               p_bias=_ptr(b), p_out=r.data_ptr())
-                node.t["wp"] = add_pack(w, Cout, Cin, True, False, wino=wants_winograd(op))
-                op.p[L.RCV_P_W] = node.t["wp"].data_ptr()
-                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
-                if bn is not None:
-                    bn_tensors(node, Cout)
-                    emit_bn_forward(node, bn, op, Cout, Ho, Wo)
-                    node.out = Value("affine" if order == "relu_bn" else "affine_relu", r, Cout, Ho, Wo, node.t["consts"], node)
-                else:
-                    fwd.append(op)
-                    node.out = Value("plain", r, Cout, Ho, Wo, None, node)
-            elif node.op == "pool":
-                src = ref(d["src"])
-                if src.H % 2 or src.W % 2:
-                    raise L.RcvError("max-pool needs even spatial dims, got %dx%d" % (src.H, src.W))
-                out = self._alloc(plan, N, src.H // 2, src.W // 2, src.C)
-                op = L.make_op(L.OP_POOL_FWD, 0, n=N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
-                               p_in_c=_ptr(src.consts), p_out=out.data_ptr())
-                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
-                fwd.append(op)
-                node.out = Value("plain", out, src.C, src.H // 2, src.W // 2, None, node)
-            elif node.op == "up":
-                src = ref(d["src"])
-                w, b, bn = d["weight"], d.get("bias"), d["bn"]
-                Cin, Cout = w.shape[0], w.shape[1]
-                if Cin != src.C:
-                    raise L.RcvError("up node %d: input has %d channels, weight expects %d" % (node.idx, src.C, Cin))
-                Ho, Wo = 2 * src.H, 2 * src.W
-                node.t["wp"] = add_pack(w, Cin, Cout, False, False, merged=use_merged(Cout))
-                t = self._alloc(plan, N, Ho, Wo, Cout)
-                bn_tensors(node, Cout)
-                op = L.make_op(L.OP_TCONV, (L.F_BIAS if b is not None else 0), n=N, h=src.H, w=src.W, cin=Cin, cout=Cout,
-                               ho=Ho, wo=Wo, stride=2, dil=1, aux0=int(use_merged(Cout)), inmode=src.load_mode, p_in_c=_ptr(src.consts),
-                               p_w=node.t["wp"].data_ptr(), p_bias=_ptr(b), p_out=t.data_ptr())
-                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
-                emit_bn_forward(node, bn, op, Cout, Ho, Wo)
-                node.t["t"] = t
-                if d.get("skip") is not None:
-                    skip = ref(d["skip"])
-                    if (skip.C, skip.H, skip.W) != (Cout, Ho, Wo):
-                        raise L.RcvError("up node %d: skip tensor %s does not match output %s" %
-                                         (node.idx, (skip.C, skip.H, skip.W), (Cout, Ho, Wo)))
-                    concat = bool(d.get("concat"))      # v2: torch.cat([layer(up), skip], 1) instead of the add (model.py:507)
-                    if not concat and FUSE_UP_INTO_CLS and Cout == 8 and skip.input_index is None and only_consumer_is_cls1x1(node.idx):
-                        # the 1x1 classifier forms relu(bn(t)) + bn(skip) itself (RCV_F_FUSED_UP): no RCV_OP_COMBINE, `up` never exists
-                        node.out = Value("fused_up", None, Cout, Ho, Wo, node.t["consts"], node)
-                        node.out.fused = (t, skip)
-                        continue
-                    Cup = 2 * Cout if concat else Cout
-                    up = self._alloc(plan, N, Ho, Wo, Cup)
-                    cop = L.make_op(L.OP_COMBINE, L.F_CONCAT if concat else 0, n=N, h=Ho, w=Wo, cout=Cout, inmode2=skip.load_mode,
-                                    p_in=t.data_ptr(), p_in_c=node.t["consts"].data_ptr(), p_in2_c=_ptr(skip.consts), p_out=up.data_ptr())
-                    cop.p[L.RCV_P_IN2] = bind_in(fwd, skip, L.RCV_P_IN2) or None
-                    fwd.append(cop)
-                    node.out = Value("plain", up, Cup, Ho, Wo, None, node)
-                else:
-                    node.out = Value("affine_relu", t, Cout, Ho, Wo, node.t["consts"], node)
-            elif node.op == "cls":
-                src = ref(d["src"])
-                w, b = d["weight"], d.get("bias")
-                Cout, Cin = w.shape[0], w.shape[1]
-                if src.kind not in ("plain", "fused_up"):
-                    raise L.RcvError("classifier input must be a materialised tensor")
-                if Cin != src.C:
-                    raise L.RcvError("classifier: input has %d channels, weight expects %d" % (src.C, Cin))
-                logits = self._alloc(plan, N, Cout, src.H, src.W)
-                if tuple(w.shape[2:]) == (1, 1) and src.kind == "fused_up":
-                    tt, skip = src.fused
-                    fwd.append(L.make_op(L.OP_CLS_FWD, L.F_FUSED_UP, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, aux0=skip.load_mode,
-                                         aux1=getattr(src, "fused_rch", 0),
-                                         p_in=tt.data_ptr(), p_in_c=src.consts.data_ptr(), p_x3=skip.buf.data_ptr(), p_x4=_ptr(skip.consts),
-                                         p_w=w.data_ptr(), p_bias=_ptr(b), p_out=logits.data_ptr()))
-                elif tuple(w.shape[2:]) == (1, 1):
-                    op = L.make_op(L.OP_CLS_FWD, 0, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, p_w=w.data_ptr(), p_bias=_ptr(b),
-                                   p_out=logits.data_ptr())
-                    op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
-                    fwd.append(op)
-                elif tuple(w.shape[2:]) == (3, 3) and Cout <= CLS3_PAD:
-                    # v2 (classSize=3): the MFMA conv with the class channels padded to 8, NHWC; then bias + NHWC -> NCHW
-                    node.t["wp"] = add_pack(w, Cout, Cin, True, False)
-                    node.t["z"] = self._alloc(plan, N, src.H, src.W, CLS3_PAD)
-                    op = L.make_op(L.OP_CONV, 0, n=N, h=src.H, w=src.W, cin=Cin, cout=CLS3_PAD, ho=src.H, wo=src.W, stride=1, dil=1,
-                                   inmode=src.load_mode, p_w=node.t["wp"].data_ptr(), p_out=node.t["z"].data_ptr())
-                    op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
-                    fwd.append(op)
-                    fwd.append(L.make_op(L.OP_NHWC_TO_NCHW, 0, n=N, h=src.H, w=src.W, cin=CLS3_PAD, cout=Cout, p_in=node.t["z"].data_ptr(),
-                                         p_bias=_ptr(b), p_out=logits.data_ptr()))
-                else:
-                    raise L.RcvError("classifier kernels %s with %d classes are not built (1x1, or 3x3 with <= %d classes)"
-                                     % (tuple(w.shape[2:]), Cout, CLS3_PAD))
-                node.out = Value("plain", logits, Cout, src.H, src.W, None, node)
-                plan.logits = logits
-                assert fwd[-1].p[L.RCV_P_OUT] == logits.data_ptr()
-                plan.logits_slots = [(len(fwd) - 1, L.RCV_P_OUT)]
-            elif node.op == "add_slice":
-                # out = value(src); out[..., 0:Ca] += value(add)      (LabelProp tail, model.py:565)
-                src, add = ref(d["src"]), ref(d["add"])
-                if (add.H, add.W) != (src.H, src.W) or add.C > src.C:
-                    raise L.RcvError("add_slice: operand shapes do not match")
-                if (FUSE_UP_INTO_CLS and not training and src.kind == "affine_relu" and src.C == 16 and add.C % 4 == 0 and add.buf is not None
-                        and add.input_index is None and src.input_index is None and add.kind in ("plain", "affine", "affine_relu")
-                        and only_consumer_is_cls1x1(node.idx)):
-                    # LabelProp's tail (model.py:563-567): the 1x1 classifier forms relu(bn(t)) and adds the skip to its first add.C input
-                    # channels itself (RCV_F_FUSED_UP with i[RCV_I_AUX1] = add.C): no RCV_OP_MATERIALIZE / RCV_OP_ADD_SLICE passes
-                    node.out = Value("fused_up", None, src.C, src.H, src.W, src.consts, node)
-                    node.out.fused = (src.buf, add)
-                    node.out.fused_rch = add.C
-                    continue
-                out = self._alloc(plan, N, src.H, src.W, src.C)
-                op = L.make_op(L.OP_MATERIALIZE, 0, n=N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
-                               p_in_c=_ptr(src.consts), p_out=out.data_ptr())
-                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
-                fwd.append(op)
-                op2 = L.make_op(L.OP_ADD_SLICE, 0, n=N, h=src.H, w=src.W, cin=add.C, cout=src.C, inmode=add.load_mode,
-                                p_in_c=_ptr(add.consts), p_out=out.data_ptr())
-                op2.p[L.RCV_P_IN] = bind_in(fwd, add, L.RCV_P_IN) or None
-                fwd.append(op2)
-                node.out = Value("plain", out, src.C, src.H, src.W, None, node)
-            elif node.op == "mat":
-                src = ref(d["src"])
-                out = self._alloc(plan, N, src.H, src.W, src.C)
-                op = L.make_op(L.OP_MATERIALIZE, 0, n=N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
-                               p_in_c=_ptr(src.consts), p_out=out.data_ptr())
-                op.p[L.RCV_P_IN] = bind_in(fwd, src, L.RCV_P_IN) or None
-                fwd.append(op)
-                node.out = Value("plain", out, src.C, src.H, src.W, None, node)
-                plan.logits = out
-                plan.logits_slots = [(len(fwd) - 1, L.RCV_P_OUT)]
-            else:
-                raise L.RcvError("unknown graph node '%s'" % node.op)
-
-        # =============================== backward ===============================
-        plan.input_grads = [None] * len(in_vals)
-        if training:
-            # which values need a gradient: everything produced by a node, plus flagged inputs
-            for node in nodes:
-                if node.op == "add_slice":
-                    raise L.RcvError("this graph is inference only (add_slice has no backward); call .eval()")
-                if node.op not in ("cls", "mat"):
-                    node.out.needs_grad = True
-
-            def grad_target(v: Value, writer_op: L.RcvOp, Ho: int, Wo: int):
-                """Configure writer_op (a dgrad-like op) to produce d loss / d v with the epilogue v's producer needs."""
-                v.grad = self._alloc(plan, N, v.H, v.W, v.C)
-                writer_op.p[L.RCV_P_OUT] = v.grad.data_ptr()
-                if v.skip_grad is not None:
-                    writer_op.flags |= L.F_RESID
-                    writer_op.p[L.RCV_P_RESID] = v.skip_grad.data_ptr()
-                prod = v.producer
-                if prod is None:
-                    plan.input_grads[v.input_index] = v.grad
-                    writer_op.i[L.RCV_I_STATS] = L.STATS_NONE
-                elif prod.op == "conv" and prod.d.get("bn") is not None:
-                    writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_ENC if _conv_order(prod.d) == "relu_bn" else L.STATS_BWD_DEC
-                    writer_op.p[L.RCV_P_EPI_AUX] = v.buf.data_ptr()
-                    writer_op.p[L.RCV_P_EPI_C] = prod.t["consts"].data_ptr()     # row 2 = batch mean
-                elif prod.op == "up" and not prod.d.get("concat"):
-                    writer_op.i[L.RCV_I_STATS] = L.STATS_BWD_DEC
-                    writer_op.p[L.RCV_P_EPI_AUX] = prod.t["t"].data_ptr()
-                    writer_op.p[L.RCV_P_EPI_C] = prod.t["consts"].data_ptr()
-                else:
-                    writer_op.i[L.RCV_I_STATS] = L.STATS_NONE
-                self._workspace(plan, writer_op)
-                if writer_op.i[L.RCV_I_STATS] != L.STATS_NONE:
-                    prod.t["bwd_part"] = (writer_op.p[L.RCV_P_PART], writer_op.i[L.RCV_I_NPART])
-
-            def emit_bn_backward(node: _Node, bn, Cc: int, Ho: int, Wo: int):
-                part_ptr, n_part = node.t["bwd_part"]
-                node.t["bconsts"] = self._zeros(plan, 5, Cc)
-                bwd.append(L.make_op(L.OP_BN_BWD, 0, n=N, ho=Ho, wo=Wo, cout=Cc, npart=n_part, p_part=part_ptr,
-                                     p_out=node.t["bconsts"].data_ptr(), p_in_c=node.t["consts"].data_ptr(),
-                                     p_x0=bn.weight.data_ptr(), p_x1=fl.grad_ptr(bn.weight), p_x2=fl.grad_ptr(bn.bias),
-                                     p_x4=node.t["mean"].data_ptr(), p_x5=node.t["istd"].data_ptr()))
-
-            def node_params(nd):
-                ps = [nd.d.get("weight"), nd.d.get("bias")]
-                bn_ = nd.d.get("bn")
-                if bn_ is not None:
-                    ps += [bn_.weight, bn_.bias]
-                return [q for q in ps if q is not None]
-
-            for node in reversed(nodes):
-                d = node.d
-                plan.bwd_marks.append([len(bwd), node])      # patched to (op count after this node, min flat offset) below
-                if node.op == "cls":
-                    src = ref(d["src"])
-                    w, b = d["weight"], d.get("bias")
-                    Cout, Cin = w.shape[0], w.shape[1]
-                    if "z" in node.t:      # 3x3 classifier: NCHW dlogits -> padded NHWC, then the ordinary filter / data gradients
-                        if src.input_index is not None:
-                            raise L.RcvError("the 3x3 classifier cannot read a graph input directly")
-                        g8 = self._alloc(plan, N, src.H, src.W, CLS3_PAD)
-                        plan.dlogits_slots.append((len(bwd), L.RCV_P_IN))
-                        bwd.append(L.make_op(L.OP_NCHW_TO_NHWC, 0, n=N, h=src.H, w=src.W, cin=Cout, cout=CLS3_PAD, p_out=g8.data_ptr()))
-                        wop = L.make_op(L.OP_WGRAD, (L.F_BIAS if b is not None else 0), n=N, h=src.H, w=src.W, cin=Cin, ho=src.H, wo=src.W,
-                                        cout=CLS3_PAD, stride=1, dil=1, inmode=src.load_mode, inmode2=L.LOAD_PLAIN,
-                                        p_in=src.buf.data_ptr(), p_in_c=_ptr(src.consts), p_in2=g8.data_ptr())
-                        self._workspace(plan, wop)
-                        bwd.append(wop)
-                        bwd.append(L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cin, cout=Cout, nsplit=wop.i[L.RCV_I_NSPLIT],
-                                             p_part=wop.p[L.RCV_P_PART], p_out=fl.grad_ptr(w),
-                                             p_bias=(fl.grad_ptr(b) if b is not None else 0)))
-                        if src.needs_grad:
-                            node.t["wd"] = add_pack(w, Cout, Cin, False, True)
-                            dop = L.make_op(L.OP_CONV, 0, n=N, h=src.H, w=src.W, cin=CLS3_PAD, cout=Cin, ho=src.H, wo=src.W, stride=1, dil=1,
-                                            inmode=L.LOAD_PLAIN, p_in=g8.data_ptr(), p_w=node.t["wd"].data_ptr())
-                            grad_target(src, dop, src.H, src.W)
-                            bwd.append(dop)
-                        continue
-                    op = L.make_op(L.OP_CLS_BWD, 0, n=N, h=src.H, w=src.W, cin=Cin, cout=Cout, p_in=src.buf.data_ptr() if src.buf is not None else 0,
-                                   p_w=w.data_ptr(), p_x1=fl.grad_ptr(w), p_x2=(fl.grad_ptr(b) if b is not None else 0))
-                    if src.kind == "fused_up":
-                        _tt, skip = src.fused
-                        op.flags |= L.F_FUSED_UP
-                        op.i[L.RCV_I_AUX0] = skip.load_mode
-                        op.p[L.RCV_P_X3] = skip.buf.data_ptr()
-                        op.p[L.RCV_P_X4] = _ptr(skip.consts) or None
-                    if src.input_index is not None:
-                        plan.input_slots[src.input_index].append((True, len(bwd), L.RCV_P_IN))
-                    plan.dlogits_slots.append((len(bwd), L.RCV_P_IN2))
-                    grad_target(src, op, src.H, src.W)
-                    bwd.append(op)
-                elif node.op == "mat":
-                    # the gradient of the materialised output arrives from outside: copy + BN-backward sums
-                    src = ref(d["src"])
-                    op = L.make_op(L.OP_BWD_STATS, 0, n=N, h=src.H, w=src.W, cout=src.C)
-                    plan.dlogits_slots.append((len(bwd), L.RCV_P_IN))
-                    grad_target(src, op, src.H, src.W)
-                    if op.i[L.RCV_I_STATS] == L.STATS_NONE:
-                        raise L.RcvError("a materialised output must follow a conv or up block")
-                    bwd.append(op)
-                elif node.op == "up":
-                    out, src = node.out, ref(d["src"])
-                    w, b, bn = d["weight"], d.get("bias"), d["bn"]
-                    Cin, Cout = w.shape[0], w.shape[1]
-                    if out.grad is None:
-                        raise L.RcvError("up node %d has no consumer that produces its gradient" % node.idx)
-                    gout = out.grad
-                    if d.get("skip") is not None and d.get("concat"):
-                        # gradient of the concatenation: channels [0,C) belong to this block (copied out together with its
-                        # BatchNorm-backward sums), channels [C,2C) to the skip tensor
-                        gout = self._alloc(plan, N, out.H, out.W, Cout)
-                        sop = L.make_op(L.OP_BWD_STATS, 0, n=N, h=out.H, w=out.W, cin=2 * Cout, cout=Cout, aux0=0, stats=L.STATS_BWD_DEC,
-                                        p_in=out.grad.data_ptr(), p_epi_aux=node.t["t"].data_ptr(), p_epi_c=node.t["consts"].data_ptr(),
-                                        p_out=gout.data_ptr())
-                        self._workspace(plan, sop)
-                        node.t["bwd_part"] = (sop.p[L.RCV_P_PART], sop.i[L.RCV_I_NPART])
-                        bwd.append(sop)
-                        gskip = self._alloc(plan, N, out.H, out.W, Cout)
-                        bwd.append(L.make_op(L.OP_BWD_STATS, 0, n=N, h=out.H, w=out.W, cin=2 * Cout, cout=Cout, aux0=Cout, stats=L.STATS_NONE,
-                                             p_in=out.grad.data_ptr(), p_out=gskip.data_ptr()))
-                        ref(d["skip"]).skip_grad = gskip
-                    elif d.get("skip") is not None:
-                        ref(d["skip"]).skip_grad = out.grad        # d up / d skip = identity
-                    emit_bn_backward(node, bn, Cout, out.H, out.W)
-                    # filter gradient: G = dt (2x plane), P = layer input
-                    wop = L.make_op(L.OP_WGRAD, 0, n=N, h=out.H, w=out.W, cin=Cout, ho=src.H, wo=src.W, cout=Cin, stride=2, dil=1,
-                                    inmode=L.LOAD_GRAD_DEC, inmode2=src.load_mode, p_in=gout.data_ptr(),
-                                    p_in_aux=node.t["t"].data_ptr(), p_in_c=node.t["bconsts"].data_ptr(),
-                                    p_in2_c=_ptr(src.consts))
-                    wop.p[L.RCV_P_IN2] = (src.buf.data_ptr() if src.buf is not None else None)
-                    if src.input_index is not None:
-                        plan.input_slots[src.input_index].append((True, len(bwd), L.RCV_P_IN2))
-                    self._workspace(plan, wop)
-                    bwd.append(wop)
-                    bwd.append(L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cout, cout=Cin, nsplit=wop.i[L.RCV_I_NSPLIT],
-                                         p_part=wop.p[L.RCV_P_PART], p_out=fl.grad_ptr(w)))
-                    if b is not None:   # bias ahead of a BatchNorm: gradient is identically zero (DESIGN.md 4.3)
-                        bwd.append(L.make_op(L.OP_MEMSET, 0, count=b.numel(), p_out=fl.grad_ptr(b)))
-                    if src.needs_grad:
-                        node.t["wd"] = add_pack(w, Cin, Cout, True, False)
-                        dop = L.make_op(L.OP_CONV, 0, n=N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=2, dil=1,
-                                        inmode=L.LOAD_GRAD_DEC, p_in=gout.data_ptr(), p_in_aux=node.t["t"].data_ptr(),
-                                        p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
-                        grad_target(src, dop, src.H, src.W)
-                        bwd.append(dop)
-                elif node.op == "pool":
-                    out, src = node.out, ref(d["src"])
-                    if out.grad is None:
-                        raise L.RcvError("pool node %d has no gradient producer" % node.idx)
-                    if src.needs_grad:
-                        pop = L.make_op(L.OP_POOL_BWD, 0, n=N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
-                                        p_in=out.grad.data_ptr(), p_in_c=_ptr(src.consts))
-                        grad_target(src, pop, src.H, src.W)
-                        # pool backward recomputes the arg-max from the producer's r; for non-BN producers use the tensor itself
-                        pop.p[L.RCV_P_EPI_AUX] = src.buf.data_ptr() if src.buf is not None else None
-                        if src.input_index is not None:
-                            plan.input_slots[src.input_index].append((True, len(bwd), L.RCV_P_EPI_AUX))
-                        if src.producer is not None and src.producer.op == "up":
-                            raise L.RcvError("max-pool directly after a decoder block is not supported")
-                        bwd.append(pop)
-                elif node.op == "conv":
-                    out, src = node.out, ref(d["src"])
-                    w, b, bn = d["weight"], d.get("bias"), d.get("bn")
-                    Cout, Cin = w.shape[0], w.shape[1]
-                    s, dil = d["stride"], d["dil"]
-                    order = _conv_order(d)
-                    if out.grad is None:
-                        raise L.RcvError("conv node %d has no gradient producer" % node.idx)
-                    if bn is not None:
-                        emit_bn_backward(node, bn, Cout, out.H, out.W)
-                    else:       # relu(conv): the gradient load is the ReLU mask alone, v = r > 0 ? 1*g + 0 + 0*r : 0
-                        ones = self._zeros(plan, 5, Cout)
-                        ones[0].fill_(1.0)
-                        node.t["bconsts"] = ones
-                    gmode = L.LOAD_GRAD_DEC if order == "bn_relu" else L.LOAD_GRAD_ENC
-                    bias_grad = b is not None and order != "bn_relu"
-                    wop = L.make_op(L.OP_WGRAD, (L.F_BIAS if bias_grad else 0), n=N, h=src.H, w=src.W, cin=Cin, ho=out.H, wo=out.W,
-                                    cout=Cout, stride=s, dil=dil, inmode=src.load_mode, inmode2=gmode,
-                                    p_in_c=_ptr(src.consts), p_in2=out.grad.data_ptr(), p_in2_aux=out.buf.data_ptr(),
-                                    p_in2_c=node.t["bconsts"].data_ptr())
-                    wop.p[L.RCV_P_IN] = (src.buf.data_ptr() if src.buf is not None else None)
-                    if src.input_index is not None:
-                        plan.input_slots[src.input_index].append((True, len(bwd), L.RCV_P_IN))
-                    self._workspace(plan, wop)
-                    bwd.append(wop)
-                    bwd.append(L.make_op(L.OP_WGRAD_REDUCE, 0, cin=Cin, cout=Cout, nsplit=wop.i[L.RCV_I_NSPLIT],
-                                         p_part=wop.p[L.RCV_P_PART], p_out=fl.grad_ptr(w),
-                                         p_bias=(fl.grad_ptr(b) if bias_grad else 0)))
-                    if b is not None and not bias_grad:   # bias ahead of a BatchNorm: gradient is identically zero
-                        bwd.append(L.make_op(L.OP_MEMSET, 0, count=b.numel(), p_out=fl.grad_ptr(b)))
-                    if src.needs_grad:
-                        if s == 1:
-                            dop = L.make_op(L.OP_CONV, 0, n=N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=1, dil=dil,
-                                            inmode=gmode, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
-                                            p_in_c=node.t["bconsts"].data_ptr())
-                            node.t["wd"] = add_pack(w, Cout, Cin, False, True, wino=wants_winograd(dop))
-                            dop.p[L.RCV_P_W] = node.t["wd"].data_ptr()
-                        else:
-                            if src.H != 2 * out.H or src.W != 2 * out.W:
-                                raise L.RcvError("stride-2 conv backward needs even input dims (got %dx%d)" % (src.H, src.W))
-                            node.t["wd"] = add_pack(w, Cout, Cin, False, False, merged=use_merged(Cin))
-                            dop = L.make_op(L.OP_TCONV, 0, n=N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=2, dil=1,
-                                            aux0=int(use_merged(Cin)),
-                                            inmode=gmode, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
-                                            p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
-                        grad_target(src, dop, src.H, src.W)
-                        bwd.append(dop)
-
-        # ---- batched filter-gradient reductions: the records keep their positions (every index into the list stays valid); all but
-        # the last reduction of a group become RCV_OP_NOP, the last one becomes the table-driven launch of the whole group ----
-        batch_at: Dict[int, int] = {}          # index of a folded reduction -> index of the launch that now carries it
-        plan.reduce_outputs = {}               # index of a batched launch -> [(gradient pointer it writes, zero-fill?)] (schedule tests)
-        if training and REDUCE_BATCH > 1:
-            idxs = [k for k, op in enumerate(bwd) if op.kind == L.OP_WGRAD_REDUCE]
-            for g0 in range(0, len(idxs), REDUCE_BATCH):
-                grp = idxs[g0:g0 + REDUCE_BATCH]
-                if len(grp) < 2:
-                    continue
-                # the bias-gradient memsets between the group's first and last reduction ride along as zero-fill jobs
-                grp = sorted(grp + [k for k in range(grp[0], grp[-1]) if bwd[k].kind == L.OP_MEMSET])
-                rjobs, first, kib, outs = [], 0, 0.0, []
-                for k in grp:
-                    op = bwd[k]
-                    if op.kind == L.OP_MEMSET:
-                        cnt = op.i[L.RCV_I_COUNT]
-                        rjobs.append(L.RcvReduceJob(part=None, dw=None, db=op.p[L.RCV_P_OUT], nsplit=0, CB=cnt, CA=0, first_block=first))
-                        first += -(-cnt // 256)
-                        outs.append((op.p[L.RCV_P_OUT], True))
-                        continue
-                    ca, cb, ns = op.i[L.RCV_I_CIN], op.i[L.RCV_I_COUT], op.i[L.RCV_I_NSPLIT]
-                    cap, cbp = (4 if ca <= 4 else _round_up(ca, 16)), _round_up(cb, 16)
-                    db = op.p[L.RCV_P_BIAS] or None
-                    rjobs.append(L.RcvReduceJob(part=op.p[L.RCV_P_PART], dw=op.p[L.RCV_P_OUT], db=db, nsplit=ns, CB=cb, CA=ca, first_block=first))
-                    first += -(-(9 * cbp * cap + (cbp if db else 0)) // 64)
-                    kib += self.op_work(op)[1] / 1024.0
-                    outs += [(q, False) for q in (op.p[L.RCV_P_OUT], db) if q]
-                table = (L.RcvReduceJob * len(rjobs))(*rjobs)
-                dev_table = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).to(self.device)
-                plan.keep.append(dev_table)
-                for k in grp[:-1]:
-                    bwd[k] = L.make_op(L.OP_NOP, 0)
-                    batch_at[k] = grp[-1]
-                bwd[grp[-1]] = L.make_op(L.OP_WGRAD_REDUCE_BATCH, 0, count=len(rjobs), npart=first, aux0=int(kib), p_in=dev_table.data_ptr())
-                batch_at[grp[-1]] = grp[-1]
-                plan.reduce_outputs[grp[-1]] = outs
-
-        # gradient-ready marks: after bwd ops [0:end) every parameter at flat offset >= lo is final (parameters are laid
-        # out in forward order and backward visits the nodes in reverse, so the finished region is a growing suffix)
-        marks, lo, prev_end = [], fl.numel, 0
-        for k, (start, node) in enumerate(plan.bwd_marks):
-            end = plan.bwd_marks[k + 1][0] if k + 1 < len(plan.bwd_marks) else len(bwd)
-            for q in range(start, end):            # a node whose reduction was folded into a later launch is final only behind that launch
-                if q in batch_at:
-                    end = max(end, batch_at[q] + 1)
-            end = prev_end = max(end, prev_end)
-            offs = [fl.offsets[fl.index(q)] for q in node_params(node)] if training else []
-            if offs:
-                lo = min(lo, min(offs))
-            if end > 0 and (not marks or marks[-1][0] != end):
-                marks.append((end, lo))
-            elif marks:
-                marks[-1] = (end, min(marks[-1][1], lo))
-        plan.bwd_marks = marks if training else []
-
-        # ---- the pack launch goes first in the forward list ----
-        head = list(pre)
-        if jobs:        # (a graph without 3x3 filters -- a lone 1x1 classifier -- packs nothing)
-            table = (L.RcvPackJob * len(jobs))(*jobs)
-            host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8)
-            dev_table = host.to(self.device)
-            plan.keep.append(dev_table)
-            assert C.sizeof(table) == dev_table.numel()
-            max_elems = max((4 if j.merged == 1 else 9) * j.rows_pad * j.cols_pad for j in jobs)
-            head = [L.make_op(L.OP_PACK, 0, count=len(jobs), aux0=max_elems, p_in=dev_table.data_ptr())] + head
-        for slots in plan.input_slots:
-            for i, (is_bwd, k, sl) in enumerate(slots):
-                if not is_bwd:
-                    slots[i] = (is_bwd, k + len(head), sl)
-        fwd = head + fwd
-        plan.n_head = len(head)
-        plan.logits_slots = [(k + len(head), sl) for (k, sl) in plan.logits_slots]
-        # backward: the filter gradients (and their reductions) are off the critical path d(loss)/d(activation) chain ->
-        # second HIP stream inside rcv_run (measured -4 % step time: their latency-bound phases fill the other kernels' gaps)
-        if SIDE_STREAM_WGRAD:
-            for op in bwd:
-                if op.kind in (L.OP_WGRAD, L.OP_WGRAD_REDUCE, L.OP_WGRAD_REDUCE_BATCH, L.OP_MEMSET):
-                    op.flags |= L.F_SIDE_STREAM
-        plan.fwd = L.OpList(fwd)
-        plan.bwd = L.OpList(bwd)
-        # plan-time validation: the library answers a query for a record exactly when it would launch it (every shape refusal sits in
-        # front of the query return), so an unsupported layer raises HERE with the library's message, not at the first backward
-        plan.fwd.labels(self.handle)
-        plan.bwd.labels(self.handle)
-        return plan
+        return _Lowering(self, shapes, training).run()
 
     # ------------------------------------------------------------------ execution
     def _param_state_key(self):
