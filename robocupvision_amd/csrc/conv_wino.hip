@@ -223,7 +223,9 @@ __global__ __launch_bounds__(W_NT) void conv_wino_kernel(const ConvArgs a) {
         for (int b = 0; b < W_TB; ++b)
           acc[x][m][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[b], acc[x][m][b], 0, 0, 0);
       if (x == 0 && j + 1 < nsteps) {
-        // V of the next k-step, formed while the matrix pipe runs this one.  Its raw chunk: the group of step j+1
+        // V of the next k-step, formed while the matrix pipe runs this one.  Its raw chunk: the group of step j+1.  (Round 3: letting the
+        // transform waves that share a SIMD -- 0 and 4, or 1 and 3 -- transform at different points of the k-step instead of together
+        // measured 1-3 % SLOWER, exp_r3_wino.sh: the barrier-aligned schedule is not what idles the matrix pipe.)
         const int g1 = (j + 1) >> 2, sub1 = (j + 1) & 3;
         v_transform(buf ^ 1, xl + (g1 & 1) * a.xl_floats + sub1 * W_CK);
       }
