@@ -2,10 +2,9 @@
 """gpurun_out/prof_TAG/{stats,fetch,write} (scripts/profile_round.sh) -> profiles/TAG_kernel_stats.csv,
 profiles/TAG_hbm_traffic.json.  PMC units and the gfx950 correction follow MI355X_MICROARCH.md (section HBM):
 FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE counts a wide (16 B/lane) coalesced read at half its bytes => x2."""
-import collections, csv, glob, json, re, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
 tag = sys.argv[1]
 base = "gpurun_out/prof_%s" % tag
-import os
 
 
 def kname(n):
@@ -22,8 +21,9 @@ def agg(path, counter):
     return d
 
 
-f = agg(glob.glob(base + "/fetch/runc/*_counter_collection.csv")[0], "FETCH_SIZE")
-w = agg(glob.glob(base + "/write/runc/*_counter_collection.csv")[0], "WRITE_SIZE")
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)      # (a directory may hold the passes of an earlier call as well)
+f = agg(newest(base + "/fetch/runc/*_counter_collection.csv"), "FETCH_SIZE")
+w = agg(newest(base + "/write/runc/*_counter_collection.csv"), "WRITE_SIZE")
 out = {}
 for k in sorted(f, key=lambda k: -f[k][0]):
     fs, n = f[k]
@@ -33,7 +33,7 @@ for k in sorted(f, key=lambda k: -f[k][0]):
 json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 5 --warmup 2`; "
                    "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches (gfx950 half-count correction on reads)",
            "kernels": out}, open("profiles/%s_hbm_traffic.json" % tag, "w"), indent=1)
-shutil.copy(glob.glob(base + "/stats/runc/*_kernel_stats.csv")[0], "profiles/%s_kernel_stats.csv" % tag)
+shutil.copy(newest(base + "/stats/runc/*_kernel_stats.csv"), "profiles/%s_kernel_stats.csv" % tag)
 shutil.copy(base + "/bench_stats.json", "profiles/%s_bench_under_rocprof.json" % tag)
 pmc = "gpurun_out/pmc_%s_conv128.txt" % tag
 if os.path.exists(pmc):
