@@ -148,29 +148,31 @@ def test_step_vs_golden_big(golden, tag):
         assert abs(got - n32) <= tol * n32 + 1e-7 or abs(got - n64) <= tol * n64 + 1e-7, (k, got, n32, n64)
 
 
-def test_full_baseline_batch_by_replication(golden):
-    """BASELINE.json's metric config itself (ROBO-UNet noScale, 32 x 640 x 480, train.py:291) is too large for a CPU golden; its
-    parity is checked through a size-independent property.  A batch made of 16 copies of the golden 2 x 640 x 480 batch has the
-    same BatchNorm batch statistics and the same mean-reduced loss as the 2-image batch, so the 32-image training step must
-    reproduce the reference's 2-image numbers: loss, per-parameter gradient norms (1e-3, the fp32 bar), the arg-max mask of EVERY
-    copy (exact outside the reference's near-tie pixels), and all copies must agree with each other bit for bit."""
-    tag = "robo_l_2x480x640"
+@pytest.mark.parametrize("tag,copies", [("robo_l_2x480x640", 16), ("robo_s_4x120x160", 16), ("unet_l_2x480x640", 16)])
+def test_full_baseline_batch_by_replication(golden, tag, copies):
+    """BASELINE.json's configs at their FULL batch -- the metric config (ROBO-UNet noScale, 32 x 640 x 480, train.py:291), config 2
+    (ROBO-UNet 64 x 160 x 120) and config 3 (U-Net noScale, 32 x 640 x 480) -- are too large for CPU goldens; their parity is checked
+    through a size-independent property.  A batch made of 16 copies of the golden batch has the same BatchNorm batch statistics and
+    the same mean-reduced loss as the golden batch itself, so the full-size training step must reproduce the reference's numbers:
+    loss, per-parameter gradient norms (1e-3, the fp32 bar), the arg-max mask of EVERY copy (exact outside the reference's
+    near-tie pixels), and all copies must agree with each other bit for bit."""
     net_kats, m = golden(tag)
     model = build(m["ctor"]).to(DEV)
-    x2, t2 = O.synthetic_batch(m["B"], m["H"], m["W"])
-    x = x2.repeat(16, 1, 1, 1).to(DEV)
-    t = t2.repeat(16, 1, 1).to(DEV)
-    assert tuple(x.shape) == (32, 3, 480, 640)
+    B, H, W = m["B"], m["H"], m["W"]
+    x2, t2 = O.synthetic_batch(B, H, W)
+    x = x2.repeat(copies, 1, 1, 1).to(DEV)
+    t = t2.repeat(copies, 1, 1).to(DEV)
+    assert tuple(x.shape) in ((32, 3, 480, 640), (64, 3, 120, 160))
     res = hip_step(model, x, t, do_step=False)
     assert abs(res["ce"] - m["ce"]) <= 1e-3 * abs(m["ce"]), (res["ce"], m["ce"])
-    pred = res["pred"].view(16, 2, 5, 480, 640)
+    pred = res["pred"].view(copies, B, 5, H, W)
     assert torch.equal(pred[1:], pred[:1].expand_as(pred[1:])), "copies of the same images differ inside one batch"
     las = float(pred[0].double().abs().sum())
     assert abs(las - m["logits_abs_sum"]) <= 1e-3 * m["logits_abs_sum"]
-    pc = res["pc"].view(16, 2, 480, 640)
-    ndiff = check_mask(pc[0], net_kats[tag + "/argmax"], net_kats[tag + "/near_tie_idx"], tag + " (copy 0 of 16)")
+    pc = res["pc"].view(copies, B, H, W)
+    ndiff = check_mask(pc[0], net_kats[tag + "/argmax"], net_kats[tag + "/near_tie_idx"], tag + " (copy 0 of %d)" % copies)
     assert torch.equal(pc[1:], pc[:1].expand_as(pc[1:]))
-    assert abs(res["correct"] - 16 * m["correct"]) <= 16 * ndiff
+    assert abs(res["correct"] - copies * m["correct"]) <= copies * ndiff
     for k, g in res["grads"].items():
         if k.startswith("upPart") and k.endswith("conv.bias"):
             continue
@@ -449,6 +451,13 @@ def test_labelprop_inference_vs_golden():
     top2 = torch.topk(ref, 2, dim=1)[0]
     near = np.nonzero(((top2[:, 0] - top2[:, 1]) < 1e-4).numpy().reshape(-1))[0]
     check_mask(torch.max(y, 1)[1], kat["argmax"], near, "labelprop mask")
+    # BASELINE config 5 at B = 64 (validLabelProp.py batches frame pairs): 32 copies of the golden pair -- inference has no coupling
+    # between samples, so every copy must carry the golden pair's logits, bit for bit the same as copy 0 and within the bar of the reference
+    with torch.no_grad():
+        y64 = net(_t(kat["x"]).repeat(32, 1, 1, 1).to(DEV)).view(32, 2, 5, 120, 160)
+    assert torch.equal(y64[1:], y64[:1].expand_as(y64[1:]))
+    close(y64[0], _t(kat["logits"]), "labelprop logits (B = 64, copy 0)")
+    check_mask(torch.max(y64[0], 1)[1], kat["argmax"], near, "labelprop mask (B = 64)")
     with pytest.raises(Exception):
         net.train()
         net(_t(kat["x"]).to(DEV))
