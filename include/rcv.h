@@ -70,8 +70,8 @@ enum {
   RCV_OP_BN_EVAL     = 7,  /* running statistics -> scale/shift                                  */
   RCV_OP_BN_BWD      = 8,  /* backward reductions -> (A,B,C) constants, dgamma, dbeta            */
   RCV_OP_COMBINE     = 9,  /* up = relu(t*s+h) + (r*s2+h2)          (decoder skip add)           */
-  RCV_OP_CLS_FWD     = 10, /* 1x1 classifier, NHWC in -> NCHW logits                             */
-  RCV_OP_CLS_BWD     = 11, /* classifier backward (dgrad + wgrad + dbias) from NCHW dlogits      */
+  RCV_OP_CLS_FWD     = 10, /* 1x1 classifier, NHWC in (8 or 16 channels) -> NCHW logits, 1..8 classes (model.py:411; numClass = 5 - nb - ng - nr - nl, train.py:301) */
+  RCV_OP_CLS_BWD     = 11, /* classifier backward (dgrad + wgrad + dbias) from NCHW dlogits, same shapes */
   RCV_OP_CE_FWD      = 12, /* weighted softmax cross-entropy forward (+argmax, +#correct)        */
   RCV_OP_CE_BWD      = 13, /* d loss / d logits                                                  */
   RCV_OP_POOL_FWD    = 14, /* 2x2/2 max-pool of (r*s+h)                                          */
@@ -181,7 +181,9 @@ typedef struct rcv_op {
 } rcv_op;
 
 /* Fills op->i[RCV_I_NPART] / [RCV_I_NSPLIT] for the tiling the library will use and returns
- * the bytes of the `part` workspace the op needs (0 if none). */
+ * the bytes of the `part` workspace the op needs (0 if none).  This query (and rcv_op_kernel_label) REFUSES exactly the records a
+ * launch would refuse for their shape -- channel counts, load modes, flag combinations; operand pointers and workspace row counts are
+ * the only things checked at launch alone -- so a caller can validate a whole op list when it builds it (RCV_E_ARG + rcv_last_error). */
 int rcv_op_workspace(const rcv_handle* h, rcv_op* op, size_t* part_bytes);
 
 /* Enqueue ops[0..n) in order on `stream`.  The handle's device is made current for the duration of the call (and the caller's
