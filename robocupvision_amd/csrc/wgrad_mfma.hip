@@ -701,6 +701,12 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     if (rc) return rc;
     rcv_plan_put(h, op, pl);
   }
+  {   // load-mode refusals belong to the shape of the record: in front of the query return (what the planner accepts, the launch accepts)
+    const int gm = op->i[RCV_I_INMODE], pm = op->i[RCV_I_INMODE2];
+    const bool g2 = gm == RCV_LOAD_GRAD_ENC || gm == RCV_LOAD_GRAD_DEC, p2 = pm == RCV_LOAD_GRAD_ENC || pm == RCV_LOAD_GRAD_DEC;
+    RCV_CHECK_ARG(pm != RCV_LOAD_NCHW, "wgrad: pointwise operand cannot be NCHW");
+    RCV_CHECK_ARG(!(g2 && p2), "wgrad: at most one operand may be a gradient (two-tensor) load");
+  }
   if (query && pl.first) {
     snprintf(query->label, sizeof(query->label), "wgrad_first<%d>", op->i[RCV_I_DIL]);
     query->n_part = 0;
@@ -730,12 +736,10 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   a.fdWt4 = make_fastdiv(pl.Wt4); a.fdIW = make_fastdiv(pl.IW);
   RCV_CHECK_ARG(a.g && a.p && a.part, "wgrad: null operand");
   RCV_CHECK_ARG(op->i[RCV_I_NSPLIT] == pl.nsplit, "wgrad: workspace splits %d != %d", op->i[RCV_I_NSPLIT], pl.nsplit);
-  RCV_CHECK_ARG(a.p_mode != RCV_LOAD_NCHW, "wgrad: pointwise operand cannot be NCHW");
   RCV_CHECK_ARG(a.g_mode == RCV_LOAD_PLAIN || a.g_mode == RCV_LOAD_NCHW || a.g_c, "wgrad: gathered load mode %d needs constants", a.g_mode);
   RCV_CHECK_ARG(a.p_mode == RCV_LOAD_PLAIN || a.p_c, "wgrad: pointwise load mode %d needs constants", a.p_mode);
   const bool g_two = a.g_mode == RCV_LOAD_GRAD_ENC || a.g_mode == RCV_LOAD_GRAD_DEC;
   const bool p_two = a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC;
-  RCV_CHECK_ARG(!(g_two && p_two), "wgrad: at most one operand may be a gradient (two-tensor) load");
   RCV_CHECK_ARG(!g_two || a.g_aux, "wgrad: gathered gradient load needs aux");
   RCV_CHECK_ARG(!p_two || a.p_aux, "wgrad: pointwise gradient load needs aux");
   a.part_bias = (op->flags & RCV_F_BIAS) ? a.part + (size_t)pl.nsplit * 9 * pl.CBP * pl.CAP : nullptr;
