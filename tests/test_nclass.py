@@ -152,7 +152,7 @@ def test_what_the_query_accepts_the_launch_would_accept():
         L.make_op(L.OP_BWD_STATS, 0, n=2, h=8, w=8, cout=6),
         L.make_op(L.OP_WGRAD, 0, n=2, h=16, w=16, cin=16, ho=16, wo=16, cout=16, stride=1, dil=1, inmode=L.LOAD_GRAD_ENC, inmode2=L.LOAD_GRAD_ENC),
         L.make_op(L.OP_WGRAD, 0, n=2, h=16, w=16, cin=16, ho=16, wo=16, cout=16, stride=1, dil=1, inmode=L.LOAD_AFFINE, inmode2=L.LOAD_NCHW),
-        L.make_op(L.OP_CONV, 0, n=2, h=16, w=16, cin=16, cout=12, ho=16, wo=16, stride=1, dil=1, inmode=L.LOAD_AFFINE),
+        L.make_op(L.OP_CONV, 0, n=2, h=16, w=16, cin=16, cout=14, ho=16, wo=16, stride=1, dil=1, inmode=L.LOAD_AFFINE),
         L.make_op(L.OP_CONV, 0, n=2, h=16, w=16, cin=16, cout=16, ho=16, wo=16, stride=3, dil=1, inmode=L.LOAD_AFFINE),
     ]
     for op in bad:
