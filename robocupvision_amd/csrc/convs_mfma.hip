@@ -574,6 +574,9 @@ int convs_make_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* p
   if (const char* ev = RCV_ENV("RCV_CONVS_TILE")) sscanf(ev, "%d,%d,%d", &ovR, &ovW, &ovWN);
   for (int WN : kNarrowWNs) {
     if (!narrow_wn_built(WN, CinP, pl->WM) || (ovWN > 0 && WN != ovWN)) continue;
+    // (Round 3, scripts/experiments/sweep_tiles.py: op by op the three-block tile measured 7 % faster than the five-block one on the merged
+    // 16 -> 8 transposed conv at 32x240x320, forward and data gradient; inside the two-stream step the same change measured +1.1 % on
+    // the STEP (6.35 -> 6.42 ms) -- what an isolated op wins it takes from the filter gradient running beside it.  Not applied.)
     const int PIX = 64 * WN;
     for (int nx = 1; nx <= TW; ++nx) {
       const int wt = ceil_div(TW, nx);

@@ -582,7 +582,11 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   // pixel tile: widest row segment, then as many rows as the prefetch registers and the LDS budget allow
   int per_cu = wt.SPEC ? 1 : 2;                     // SPEC: 512 threads, two LDS buffers => one workgroup per CU
   if (const char* ev = RCV_ENV("RCV_WGRAD_OCC")) { const int o = atoi(ev); if (o >= 1 && o <= 4 && !wt.SPEC) per_cu = o; }
-  const size_t budget = (wt.SPEC ? 78 : 160 / per_cu) * 1024 / sizeof(float);   // SPEC: per buffer
+  // SPEC: per buffer.  (Round 3: the sweep of scripts/experiments/sweep_tiles.py found the 5 x 20 tile of the 64 x 64 producer/consumer
+  // kernel -- 79.4 KB per buffer, i.e. ALL of the CU's LDS -- 4 % faster than the 3 x 20 tile this budget allows, 118 -> 113.5 us on the
+  // 128 -> 128 layers; inside the step it measured 0.6 % SLOWER: with 108 KB the kernel leaves room for a narrow data-gradient workgroup
+  // of the other stream on the same CU, with 159 KB it does not.  The budget stays.)
+  const size_t budget = (wt.SPEC ? 78 : 160 / per_cu) * 1024 / sizeof(float);
   // Pixel tile: among the (row segment, rows) shapes that fit the LDS budget, the one with the lowest estimated time
   //     t ~ (1 + 3 / k-steps per wave and tile) / fill  +  w * halo,
   //   fill = real pointwise pixels / MFMA pixel slots of the launch (row segments padded to 4 columns, ragged last tiles, workgroups
@@ -640,6 +644,10 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
       }
       if (wide_first && bestR) break;
     }
+  }
+  if (const char* ev = RCV_ENV("RCV_WGRAD_TILE")) {      // experiments build: "R,Wt" (scripts/experiments/sweep_tiles.py); the LDS check below still applies
+    int r = 0, wt = 0;
+    if (sscanf(ev, "%d,%d", &r, &wt) == 2 && r >= 1 && r <= Hp && wt >= 1 && wt <= Wp) { bestR = r; bestWt = wt; }
   }
   RCV_CHECK_ARG(bestR > 0, "wgrad: no pixel tile fits (plane %dx%d)", Hp, Wp);
   const int R = ceil_div(Hp, ceil_div(Hp, bestR));

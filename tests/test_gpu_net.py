@@ -295,7 +295,7 @@ def test_scheduling_variants_are_bitwise_identical(monkeypatch):
 
 def test_backward_schedule_is_measured_once_per_plan():
     """engine.SIDE_STREAM_MODE == "auto": the first backward pass of a plan times the list under the three schedules of
-    Engine.SIDE_MODES and keeps the fastest; the measurement re-runs the list, which must not change any result."""
+    Engine.SIDE_MODES and keeps the two-stream one unless another is clearly (3 %) faster; the measurement re-runs the list, which must not change any result."""
     x, t = O.synthetic_batch(2, 48, 64)
     model = build(dict(noScale=True)).to(DEV)
     a = hip_step(model, x.to(DEV), t.to(DEV), do_step=False)
@@ -304,7 +304,9 @@ def test_backward_schedule_is_measured_once_per_plan():
     assert len(plans) == 1 and plans[0].side_decided
     if plans[0].side_ms is not None:                     # (None when the schedule is forced by the environment)
         assert len(plans[0].side_ms) == 3 and min(plans[0].side_ms) > 0
-        assert plans[0].side_mode == eng.SIDE_MODES[plans[0].side_ms.index(min(plans[0].side_ms))]
+        ms = plans[0].side_ms                            # "all" unless another schedule measured more than 3 % faster
+        best = ms.index(min(ms))
+        assert plans[0].side_mode == eng.SIDE_MODES[best if ms[best] < 0.97 * ms[0] else 0]
         assert plans[0].side_on == (plans[0].side_mode != "off")
     b = hip_step(model, x.to(DEV), t.to(DEV), do_step=False)      # second step: no measurement, same numbers
     for k in a["grads"]:
