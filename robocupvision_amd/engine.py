@@ -37,7 +37,11 @@ FUSE_UP_INTO_CLS = not os.environ.get("RCV_NO_FUSED_UP")
 # Filter-gradient reductions per batched launch (RCV_OP_WGRAD_REDUCE_BATCH): the reductions of up to this many consecutive layers of the
 # backward list run as ONE launch at the position of the last of them (18 launches at the ~5 us floor of a dependent launch -> 3).
 # 0 / 1: one launch per layer.
+# Data-parallel runs keep 6 (a bucket's gradients are final only behind the launch that reduces them: three launches = three buckets to
+# overlap with backward); a single-GPU step folds ALL reductions into one launch at the end of the list (24 covers every network here):
+# measured 6.36 against 6.39 ms on the headline step.  RCV_REDUCE_BATCH overrides both.
 REDUCE_BATCH = min(int(os.environ.get("RCV_REDUCE_BATCH", "6")), 24)      # (the job table of one launch holds at most 64 rows)
+REDUCE_BATCH_SINGLE = min(int(os.environ.get("RCV_REDUCE_BATCH", "24")), 24)
 CLS3_PAD = 8                    # class channels of the 3x3 classifier (v2) are padded to this many NHWC channels
 # Backward list order inside a layer.  Default: the layer's filter gradient and its reduction (side stream) are enqueued AHEAD of its
 # data-gradient op.  RCV_DGRAD_FIRST=1 enqueues the data gradient (the critical d loss / d activation chain) first so that its kernel is
@@ -695,10 +699,11 @@ class _Lowering:
         # ---- batched filter-gradient reductions: the records keep their positions (every index into the list stays valid); all but
         # the last reduction of a group become RCV_OP_NOP, the last one becomes the table-driven launch of the whole group ----
         plan.reduce_outputs = {}               # index of a batched launch -> [(gradient pointer it writes, zero-fill?)] (schedule tests)
-        if training and REDUCE_BATCH > 1:
+        n_batch = REDUCE_BATCH if self.eng.grad_ready_cb is not None or self.eng.dry_run else REDUCE_BATCH_SINGLE
+        if training and n_batch > 1:
             idxs = [k for k, op in enumerate(bwd) if op.kind == L.OP_WGRAD_REDUCE]
-            for g0 in range(0, len(idxs), REDUCE_BATCH):
-                grp = idxs[g0:g0 + REDUCE_BATCH]
+            for g0 in range(0, len(idxs), n_batch):
+                grp = idxs[g0:g0 + n_batch]
                 if len(grp) < 2:
                     continue
                 # the bias-gradient memsets between the group's first and last reduction ride along as zero-fill jobs
