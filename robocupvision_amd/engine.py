@@ -38,8 +38,8 @@ FUSE_UP_INTO_CLS = not os.environ.get("RCV_NO_FUSED_UP")
 # backward list run as ONE launch at the position of the last of them (18 launches at the ~5 us floor of a dependent launch -> 3).
 # 0 / 1: one launch per layer.
 # Data-parallel runs keep 6 (a bucket's gradients are final only behind the launch that reduces them: three launches = three buckets to
-# overlap with backward); a single-GPU step folds ALL reductions into one launch at the end of the list (24 covers every network here):
-# measured 6.36 against 6.39 ms on the headline step.  RCV_REDUCE_BATCH overrides both.
+# overlap with backward); a single-GPU step on large planes folds ALL reductions into one launch at the end of the list (24 covers every
+# network here): measured 6.36 against 6.39 ms on the headline step.  RCV_REDUCE_BATCH overrides both.
 REDUCE_BATCH = min(int(os.environ.get("RCV_REDUCE_BATCH", "6")), 24)      # (the job table of one launch holds at most 64 rows)
 REDUCE_BATCH_SINGLE = min(int(os.environ.get("RCV_REDUCE_BATCH", "24")), 24)
 CLS3_PAD = 8                    # class channels of the 3x3 classifier (v2) are padded to this many NHWC channels
@@ -699,7 +699,10 @@ class _Lowering:
         # ---- batched filter-gradient reductions: the records keep their positions (every index into the list stays valid); all but
         # the last reduction of a group become RCV_OP_NOP, the last one becomes the table-driven launch of the whole group ----
         plan.reduce_outputs = {}               # index of a batched launch -> [(gradient pointer it writes, zero-fill?)] (schedule tests)
-        n_batch = REDUCE_BATCH if self.eng.grad_ready_cb is not None or self.eng.dry_run else REDUCE_BATCH_SINGLE
+        # (single-GPU: one launch for everything on the large planes -- 640x480: headline -0.3 %, U-Net -0.8 %, v2 -0.6 %; three launches
+        # where the step is short and the lone launch at the end of the list is a tail nothing overlaps -- 320x240: +1.1 %, 160x120: +0.3 %)
+        big = self.N * max(v.H * v.W for v in self.in_vals) >= 5_000_000
+        n_batch = REDUCE_BATCH if (self.eng.grad_ready_cb is not None or self.eng.dry_run or not big) else REDUCE_BATCH_SINGLE
         if training and n_batch > 1:
             idxs = [k for k, op in enumerate(bwd) if op.kind == L.OP_WGRAD_REDUCE]
             for g0 in range(0, len(idxs), n_batch):
