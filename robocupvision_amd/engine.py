@@ -139,9 +139,9 @@ class _Node:
 class FlatParams:
     """All parameters in one flat fp32 device buffer; nn.Parameters become views of it."""
 
-    def __init__(self, params: Sequence[torch.nn.Parameter]):
+    def __init__(self, params: Sequence[torch.nn.Parameter], device: Optional[torch.device] = None):
         self.params = list(params)
-        dev = self.params[0].device
+        dev = self.params[0].device if self.params else device      # (a parameter-free graph -- a lone max-pool -- lives where its input does)
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
@@ -356,6 +356,9 @@ class _Lowering:
         op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
         self.fwd.append(op)
         node.out = Value("plain", out, src.C, src.H // 2, src.W // 2, None, node)
+        if node.idx == len(self.nodes) - 1:      # a graph that ENDS in the pool (standalone Pool module, model.py:92-100): its output is the result
+            self.plan.logits = out
+            self.plan.logits_slots = [(len(self.fwd) - 1, L.RCV_P_OUT)]
 
     def fwd_up(self, node: _Node):
         d = node.d
@@ -612,11 +615,14 @@ class _Lowering:
     def bwd_pool(self, node: _Node):
         d = node.d
         out, src = node.out, self.ref(d["src"])
-        if out.grad is None:
+        last = node.idx == len(self.nodes) - 1      # the graph's result: its gradient arrives from outside (patched per call)
+        if out.grad is None and not last:
             raise L.RcvError("pool node %d has no gradient producer" % node.idx)
         if src.needs_grad:
             pop = L.make_op(L.OP_POOL_BWD, 0, n=self.N, h=src.H, w=src.W, cout=src.C, inmode=src.load_mode,
-                            p_in=out.grad.data_ptr(), p_in_c=_ptr(src.consts))
+                            p_in=(None if last else out.grad.data_ptr()), p_in_c=_ptr(src.consts))
+            if last:
+                self.plan.dlogits_slots.append((len(self.bwd), L.RCV_P_IN))
             self.grad_target(src, pop, src.H, src.W)
             # pool backward recomputes the arg-max from the producer's r; for non-BN producers use the tensor itself
             pop.p[L.RCV_P_EPI_AUX] = src.buf.data_ptr() if src.buf is not None else None
@@ -822,18 +828,18 @@ class Engine:
             if self.flat is None or not self.flat.intact() or self.device != dev:
                 self.device = dev
                 self.handle = L.planner_handle(256)
-                self.flat = FlatParams(self.param_list)
+                self.flat = FlatParams(self.param_list, dev)
                 self.plans.clear()
             return
         if dev.type != "cuda":
             raise L.RcvError("robocupvision_amd computes on an MI355X (HIP) device only; got a tensor on '%s'. "
                              "There is no CPU path: move the model and inputs to cuda." % dev)
-        if self.param_list[0].device != dev:
+        if self.param_list and self.param_list[0].device != dev:
             raise L.RcvError("model parameters are on %s but the input is on %s" % (self.param_list[0].device, dev))
         if self.flat is None or not self.flat.intact() or self.device != dev:
             self.device = dev
             self.handle = L.handle(dev.index if dev.index is not None else torch.cuda.current_device())
-            self.flat = FlatParams(self.param_list)
+            self.flat = FlatParams(self.param_list, dev)
             self.plans.clear()
 
     def _alloc(self, plan: Plan, *shape, dtype=torch.float32) -> torch.Tensor:

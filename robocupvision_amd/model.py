@@ -123,9 +123,9 @@ class _BlockMixin(_EngineOwner):
 # ------------------------------------------------------------------------------------------
 # building blocks (reference: model.py:92-124, 166-199, 379-414)
 # ------------------------------------------------------------------------------------------
-class Pool(nn.Module):
+class Pool(_BlockMixin, nn.Module):
     """MaxPool2d(2,2) (model.py:92-103).  Parameter-free; inside a network it is fused with the
-    producer's BatchNorm apply."""
+    producer's BatchNorm apply; called on its own (NCHW in, NCHW out, like the reference's module) it is a one-node graph."""
 
     def __init__(self, ch, stride=2):
         super().__init__()
@@ -135,8 +135,13 @@ class Pool(nn.Module):
         self.stride = stride
         self.pool = nn.MaxPool2d(stride, stride)     # container for repr/state parity only
 
+    def _block_graph(self):
+        return {"inputs": [{"layout": "nhwc", "requires_grad": True}], "nodes": [{"op": "pool", "src": ("in", 0)}]}
+
     def forward(self, x):
-        raise L.RcvError("Pool is executed as part of its network graph (ROBO_UNet(pool=True)); standalone use is not built")
+        if x.dim() != 4 or x.shape[1] % 4 or x.shape[2] % 2 or x.shape[3] % 2:
+            raise ValueError("Pool expects float32 [B,C,H,W] with C a multiple of 4 and even H, W (got %s)" % (tuple(x.shape),))
+        return self._block_forward(x.to(torch.float32))
 
     def getComp(self, W, H, pruned):
         return W * H * self.ch, W // self.stride, H // self.stride

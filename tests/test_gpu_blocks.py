@@ -144,6 +144,26 @@ def test_maxpool_kat(layer_kats, first):
     assert float(gx[:, rest].abs().max()) == 0.0
 
 
+def test_standalone_pool_module_kat(layer_kats):
+    """The reference's Pool module called on its own (model.py:92-100: NCHW in, NCHW out, autograd): forward and backward bit-exact against
+    its pool/* vectors (a max and a routing of the gradient: integer-like work), in training mode (copy of the engine's buffer) and in
+    eval mode (fresh output tensor)."""
+    pool = M.Pool(8).to(DEV)
+    x = _t(layer_kats["pool/x"]).to(DEV).requires_grad_(True)
+    y = pool(x)
+    assert torch.equal(y.cpu(), _t(layer_kats["pool/y"]))
+    y.backward(_t(layer_kats["pool/gy"]).to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(x.grad.cpu(), _t(layer_kats["pool/gx"]))
+    pool.eval()
+    with torch.no_grad():
+        y2 = pool(x.detach())
+        y3 = pool(x.detach() * 2)
+    assert torch.equal(y2.cpu(), _t(layer_kats["pool/y"])) and torch.equal(y3, 2 * y2) and y3.data_ptr() != y2.data_ptr()
+    with pytest.raises(ValueError):
+        pool(torch.zeros(1, 8, 5, 6, device=DEV))
+
+
 @pytest.mark.parametrize("name,cin,cout", [("up_16_8", 16, 8), ("up_64_32", 64, 32), ("up_128_64", 128, 64)])
 def test_up_block(layer_kats, name, cin, cout):
     mod = _load_block(layer_kats, name, M.upSampleTransposeConv(cin, cout))
