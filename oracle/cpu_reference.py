@@ -22,6 +22,7 @@ restatement issues the same operator sequence on CPU tensors:
     train step body                      train.py:43-74          train_step()
     LabelProp.forward / ConvPoolSimple   model.py:538-567,166-176 labelprop_forward()
     labelToPred                          transform.py:172-183    label_to_pred()
+    valid() mask loops                   train.py:127,136-163    valid_metrics()
 
 Parity pinning: ``tests/test_oracle_golden.py`` checks this file bit-for-bit (8 threads)
 against golden vectors produced by importing the real reference in the build container
@@ -343,6 +344,36 @@ def pb_train_step(st: PBTrainState, imgs: Tensor, targets: Tensor, do_step: bool
     _, pred_class = torch.max(pred, 1)
     return {"pred": pred.detach(), "loss": float(loss.item()), "pred_class": pred_class,
             "correct": int(torch.sum(pred_class == targets).item())}
+
+
+def valid_metrics(pred_class: Tensor, targets: Tensor, num_class: int) -> Dict[str, object]:
+    """The mask loops of valid() (train.py:136-163; test.py:148-169 has the same shape): per image and (pred, label) pair the
+    intersection counts -> confusion matrix in per cent of the label's pixels, per-image IoU (1 where the class is absent from both
+    masks), pixel accuracy.  Restated with the reference's own fp32 accumulators; pure-Python loops: small cases only.
+    (No reference fixture exists for these numbers -- valid() needs the dataset, cv2 and progressbar: "parity unpinned" -- the
+    restatement follows the source lines one for one.)"""
+    B = pred_class.shape[0]
+    conf, iou, lab_cnts = torch.zeros(num_class, num_class), torch.zeros(num_class), torch.zeros(num_class)
+    running_acc = 0.0
+    out_size = 1.0 / float(pred_class[0].numel())                         # train.py:286 outSize = 1 / (H*W)
+    running_acc += torch.sum(pred_class == targets).item() * out_size * 100     # train.py:127
+    mask_pred = torch.stack([pred_class == c for c in range(num_class)])        # train.py:136-140
+    mask_tgt = torch.stack([targets == c for c in range(num_class)])
+    for img in range(B):                                                  # train.py:142-153
+        for lab in range(num_class):
+            lab_cnts[lab] += torch.sum(mask_tgt[lab, img]).item()
+            for prd in range(num_class):
+                inter = torch.sum(mask_pred[prd, img] & mask_tgt[lab, img]).item()
+                conf[(prd, lab)] += inter
+                if lab == prd:
+                    union = torch.sum(mask_pred[prd, img] | mask_tgt[lab, img]).item()
+                    iou[lab] += 1 if union == 0 else inter / union
+    for lab in range(num_class):                                          # train.py:157-159
+        for prd in range(num_class):
+            conf[(prd, lab)] /= (lab_cnts[lab] / 100.0)
+    mean_iou = torch.sum(iou / B).item() / num_class * 100                # train.py:161
+    mean_class_acc = sum(float(conf[(j, j)]) for j in range(num_class)) / num_class      # train.py:162-163
+    return {"pixel_acc": running_acc / B, "mean_class_acc": mean_class_acc, "mean_iou": mean_iou, "confusion_percent": conf}
 
 
 def label_to_pred(label: Tensor, num_class: int) -> Tensor:

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import cpu_reference as O
 import robocupvision_amd.model as M
 
 pytestmark = pytest.mark.gpu
@@ -222,23 +223,14 @@ def test_device_metrics_match_reference_loops():
     tgt = torch.randint(0, C, (B, H, W), generator=g)
     tgt[1][tgt[1] == 3] = 0                     # a class absent from one image (union == 0 branch)
     pred[1][pred[1] == 3] = 1
-    conf = torch.zeros(C, C); iou = torch.zeros(C); lab = torch.zeros(C)
-    for n in range(B):
-        for l in range(C):
-            lab[l] += int((tgt[n] == l).sum())
-            for p_ in range(C):
-                inter = int(((pred[n] == p_) & (tgt[n] == l)).sum())
-                conf[p_, l] += inter
-                if l == p_:
-                    union = int(((pred[n] == p_) | (tgt[n] == l)).sum())
-                    iou[l] += 1 if union == 0 else inter / union
-    ref_cls = sum(float(conf[j, j] / (lab[j] / 100.0)) for j in range(C)) / C
-    ref_iou = float((iou / B).sum()) / C * 100
+    ref = O.valid_metrics(pred, tgt, C)                                          # the oracle's restatement of train.py:127,136-163
+    ref_cls, ref_iou = ref["mean_class_acc"], ref["mean_iou"]
     m = SegmentationMetrics(C, DEV)
     m.update(pred.to(torch.uint8).to(DEV), tgt.to(DEV))
     out = m.compute()
     assert abs(out["mean_class_acc"] - ref_cls) < 1e-4 and abs(out["mean_iou"] - ref_iou) < 1e-4      # the loop reference is fp32
-    assert abs(out["pixel_acc"] - float((pred == tgt).sum()) / pred.numel() * 100) < 1e-9
+    assert abs(out["pixel_acc"] - float((pred == tgt).sum()) / pred.numel() * 100) < 1e-9 and abs(out["pixel_acc"] - ref["pixel_acc"]) < 1e-4
+    assert float((out["confusion_percent"].float() - ref["confusion_percent"]).abs().max()) < 1e-3
 
 
 @pytest.mark.parametrize("N,H,W,dil,mode2", [(2, 37, 70, 1, "grad_enc"), (1, 19, 131, 2, "grad_dec"), (3, 8, 64, 1, "plain"),

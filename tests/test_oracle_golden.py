@@ -227,3 +227,27 @@ def test_labelprop_oracle_vs_reference_on_shipped_weights():
         torch.set_num_threads(old)
     assert torch.equal(got, want)
     assert len(sd) == 55 and sum(v.numel() for v in sd.values()) == 92837      # 55 keys / 92 837 elements
+
+
+def test_valid_metrics_restatement_is_self_consistent():
+    """valid()'s mask loops (train.py:127,136-163) as restated in the oracle against an independent, vectorised evaluation of the same
+    definitions (confusion in per cent of the label's pixels, per-image IoU with 1 for a class absent from both masks).  The reference
+    holds no fixture for these numbers (valid() needs the dataset): parity unpinned, the restatement follows the lines one for one."""
+    g = torch.Generator().manual_seed(11)
+    C, B, H, W = 5, 4, 12, 20
+    pred = torch.randint(0, C, (B, H, W), generator=g)
+    tgt = torch.randint(0, C, (B, H, W), generator=g)
+    tgt[2][tgt[2] == 4] = 1
+    pred[2][pred[2] == 4] = 0                    # class 4 absent from image 2: IoU counts 1 there
+    r = O.valid_metrics(pred, tgt, C)
+    onehot_p = torch.nn.functional.one_hot(pred, C).double()
+    onehot_t = torch.nn.functional.one_hot(tgt, C).double()
+    counts = torch.einsum("bhwp,bhwl->bpl", onehot_p, onehot_t)                  # [B][pred][label]
+    conf = counts.sum(0) / (counts.sum((0, 1)) / 100.0)
+    inter = torch.diagonal(counts, dim1=1, dim2=2)
+    union = counts.sum(2) + counts.sum(1) - inter
+    iou = torch.where(union == 0, torch.ones_like(inter), inter / union.clamp(min=1)).sum(0) / B
+    assert float((r["confusion_percent"].double() - conf).abs().max()) < 1e-3
+    assert abs(r["mean_iou"] - float(iou.sum()) / C * 100) < 1e-3
+    assert abs(r["mean_class_acc"] - float(torch.diagonal(conf).sum()) / C) < 1e-3
+    assert abs(r["pixel_acc"] - float((pred == tgt).double().mean()) * 100) < 1e-6
