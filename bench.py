@@ -341,8 +341,8 @@ def launch_ranks(n: int, argv) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)       # >= 50 timed steps, >= 10 warm-up; the line carries mean AND median
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="robo_unet_640x480_bs32", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch size")
     ap.add_argument("--dice", action="store_true", help="train with DiceLoss (train.py --useDice) instead of the cross entropy")
