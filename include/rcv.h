@@ -67,7 +67,7 @@ enum {
   RCV_OP_WGRAD_REDUCE= 4,  /* fixed-order sum of WGRAD partials -> parameter-layout gradient     */
   RCV_OP_PACK        = 5,  /* parameter tensors -> kernel filter layout, table driven            */
   RCV_OP_BN_FINALIZE = 6,  /* batch statistics -> scale/shift (+ running stats)                  */
-  RCV_OP_BN_EVAL     = 7,  /* running statistics -> scale/shift                                  */
+  RCV_OP_BN_EVAL     = 7,  /* running statistics -> scale/shift; row 3 = bias folded through the BatchNorm: (p[X4] ? bias : 0)*scale + shift */
   RCV_OP_BN_BWD      = 8,  /* backward reductions -> (A,B,C) constants, dgamma, dbeta            */
   RCV_OP_COMBINE     = 9,  /* up = relu(t*s+h) + (r*s2+h2)          (decoder skip add)           */
   RCV_OP_CLS_FWD     = 10, /* 1x1 classifier, NHWC in (8 or 16 channels) -> NCHW logits, 1..8 classes (model.py:411; numClass = 5 - nb - ng - nr - nl, train.py:301) */
@@ -223,6 +223,8 @@ typedef struct rcv_pack_job {
   int32_t merged;         /* 1: transposed-conv "merged parity" layout [4 taps (dy,dx)][rows][4*cols] (see conv_mfma.hip);
                            * 2: Winograd layout [16][rows][cols] = G g G^T (see conv_wino.hip)                                  */
   int32_t reserved;
+  const float* scale; /* NULL, or one factor per OUTPUT channel (column) applied while packing: inference folds an eval-mode BatchNorm
+                       * that follows the conv directly (relu(bn(conv(x))), model.py:175,190-194) into the filter, w'[co] = w[co] * scale[co] */
 } rcv_pack_job;
 
 /* One row of the RCV_OP_WGRAD_REDUCE_BATCH job table: the arguments of one RCV_OP_WGRAD_REDUCE record. `first_block` = number of

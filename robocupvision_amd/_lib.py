@@ -38,7 +38,7 @@ class RcvOp(C.Structure):
 class RcvPackJob(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("D0", C.c_int32), ("D1", C.c_int32),
                 ("rows_from_d1", C.c_int32), ("flip", C.c_int32), ("rows_pad", C.c_int32), ("cols_pad", C.c_int32),
-                ("merged", C.c_int32), ("reserved", C.c_int32)]
+                ("merged", C.c_int32), ("reserved", C.c_int32), ("scale", C.c_void_p)]
 
 
 class RcvReduceJob(C.Structure):      # struct rcv_reduce_job of include/rcv.h

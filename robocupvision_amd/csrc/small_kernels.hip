@@ -41,8 +41,9 @@ __global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
       float g[3][3];
       const bool ok = row < rows && col < cols;
       const int d0 = jb.rows_from_d1 ? col : row, d1 = jb.rows_from_d1 ? row : col;
+      const float sc = (ok && jb.scale) ? jb.scale[col] : 1.f;       // (G g G^T is linear in g: the per-channel factor commutes)
 #pragma unroll
-      for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = ok ? jb.src[((size_t)d0 * jb.D1 + d1) * 9 + (jb.flip ? 8 - t : t)] : 0.f;
+      for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = ok ? sc * jb.src[((size_t)d0 * jb.D1 + d1) * 9 + (jb.flip ? 8 - t : t)] : 0.f;
       float tg[4][3];      // G g
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
@@ -87,6 +88,7 @@ __global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
       const int d0 = jb.rows_from_d1 ? col : row;
       const int d1 = jb.rows_from_d1 ? row : col;
       v = jb.src[((size_t)d0 * jb.D1 + d1) * 9 + ts];
+      if (jb.scale) v *= jb.scale[col];
     }
     jb.dst[e] = v;
   }
@@ -142,14 +144,18 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int n_part, i
 }
 
 __global__ void bn_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                               const float* __restrict__ rm, const float* __restrict__ rv, float eps, float* consts) {
+                               const float* __restrict__ rm, const float* __restrict__ rv, float eps, float* consts,
+                               const float* __restrict__ conv_bias) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) {
     const float istd = 1.f / sqrtf(rv[c] + eps);
     const float sc = gamma[c] * istd;
+    const float sh = beta[c] - rm[c] * sc;
     consts[0 * C + c] = sc;
-    consts[1 * C + c] = beta[c] - rm[c] * sc;
-    consts[2 * C + c] = 0.f; consts[3 * C + c] = 0.f; consts[4 * C + c] = 0.f;
+    consts[1 * C + c] = sh;
+    consts[2 * C + c] = 0.f;
+    consts[3 * C + c] = fmaf(conv_bias ? conv_bias[c] : 0.f, sc, sh);      // the conv's bias seen through the BatchNorm (inference folding)
+    consts[4 * C + c] = 0.f;
   }
 }
 
@@ -1237,7 +1243,7 @@ int rcv_launch_small(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
       RCV_CHECK_ARG(op->p[RCV_P_OUT] && op->p[RCV_P_X0] && op->p[RCV_P_X1] && op->p[RCV_P_X2] && op->p[RCV_P_X3], "bn_eval: null operand");
       hipLaunchKernelGGL(bn_eval_kernel, dim3(ceil_div(Cout, 64)), dim3(64), 0, s, Cout, (const float*)op->p[RCV_P_X0],
                          (const float*)op->p[RCV_P_X1], (const float*)op->p[RCV_P_X2], (const float*)op->p[RCV_P_X3], op->f[1],
-                         (float*)op->p[RCV_P_OUT]);
+                         (float*)op->p[RCV_P_OUT], (const float*)op->p[RCV_P_X4]);
       break;
     }
     case RCV_OP_BN_BWD: {

@@ -42,6 +42,12 @@ FUSE_UP_INTO_CLS = not os.environ.get("RCV_NO_FUSED_UP")
 # network here): measured 6.36 against 6.39 ms on the headline step.  RCV_REDUCE_BATCH overrides both.
 REDUCE_BATCH = min(int(os.environ.get("RCV_REDUCE_BATCH", "6")), 24)      # (the job table of one launch holds at most 64 rows)
 REDUCE_BATCH_SINGLE = min(int(os.environ.get("RCV_REDUCE_BATCH", "24")), 24)
+# Inference on graphs whose BatchNorms all follow their conv directly (relu(bn(conv(x))): ConvPoolSimple model.py:175, ConvPool model.py:140-142,
+# upSampleTransposeConv model.py:190-194 -- LabelProp and PB_FCN): the eval-mode BatchNorm is folded into the filter while it is packed
+# (w'[co] = w[co]*scale[co]) and into the bias (b*scale + shift), the ReLU runs in the conv's epilogue and the skip add of a decoder
+# block rides in its transposed conv's epilogue as a residual: every stored tensor is a final activation, no load transform, no
+# RCV_OP_COMBINE launches.  (ROBO_UNet's Conv is bn(relu(conv)), model.py:115-116: the ReLU sits between conv and BatchNorm, nothing folds.)
+EVAL_FOLD_BN = not os.environ.get("RCV_NO_EVAL_FOLD")
 CLS3_PAD = 8                    # class channels of the 3x3 classifier (v2) are padded to this many NHWC channels
 # Backward list order inside a layer.  Default: the layer's filter gradient and its reduction (side stream) are enqueued AHEAD of its
 # data-gradient op.  RCV_DGRAD_FIRST=1 enqueues the data gradient (the critical d loss / d activation chain) first so that its kernel is
@@ -239,6 +245,9 @@ class _Lowering:
         self.bn_finalize_flags = L.F_TRAINING if training else 0
         self.batch_at: Dict[int, int] = {}          # index of a folded reduction -> index of the launch that now carries it
         self._late: List[tuple] = []                # side-stream ops of the node being lowered, emitted behind its data-gradient op
+        bn_nodes = [d for d in g["nodes"] if d.get("bn") is not None]
+        self.fold = (EVAL_FOLD_BN and not training and bool(bn_nodes) and not any(d.get("concat") for d in g["nodes"])
+                     and all(d["op"] == "up" or _conv_order(d) == "bn_relu" for d in bn_nodes))
 
     def ref(self, r) -> Value:
         return self.in_vals[r[1]] if r[0] == "in" else self.nodes[r[1]].out
@@ -250,7 +259,7 @@ class _Lowering:
             return 0
         return v.buf.data_ptr()
 
-    def add_pack(self, param, D0, D1, rows_from_d1, flip, merged=False, wino=False):
+    def add_pack(self, param, D0, D1, rows_from_d1, flip, merged=False, wino=False, scale: Optional[torch.Tensor] = None):
         rows = D1 if rows_from_d1 else D0
         cols = D0 if rows_from_d1 else D1
         rp, cp = _round_up(rows, 4), _round_up(cols * (4 if merged else 1), 16)
@@ -259,6 +268,7 @@ class _Lowering:
         j.src, j.dst, j.D0, j.D1 = param.data_ptr(), dst.data_ptr(), D0, D1
         j.rows_from_d1, j.flip, j.rows_pad, j.cols_pad = int(rows_from_d1), int(flip), rp, cp
         j.merged = 2 if wino else int(merged)
+        j.scale = scale.data_ptr() if scale is not None else None      # per output channel (inference BatchNorm folding)
         self.jobs.append(j)
         return dst
 
@@ -292,7 +302,7 @@ class _Lowering:
         node.t["mean"] = self.eng._zeros(self.plan, Cc)
         node.t["istd"] = self.eng._zeros(self.plan, Cc)
 
-    def emit_bn_forward(self, node: _Node, bn, conv_op: L.RcvOp, Cc: int, Ho: int, Wo: int):
+    def emit_bn_forward(self, node: _Node, bn, conv_op: L.RcvOp, Cc: int, Ho: int, Wo: int, conv_bias=None):
         """Statistics partials of conv_op -> constants (training) or running stats -> constants (eval)."""
         if self.training:
             if self.N * Ho * Wo <= 1:      # same refusal (and text) as torch.nn.functional.batch_norm, which the reference runs
@@ -309,7 +319,7 @@ class _Lowering:
         else:
             self.pre.append(L.make_op(L.OP_BN_EVAL, 0, cout=Cc, f1=BN_EPS, p_out=node.t["consts"].data_ptr(),
                                  p_x0=bn.weight.data_ptr(), p_x1=bn.bias.data_ptr(),
-                                 p_x2=bn.running_mean.data_ptr(), p_x3=bn.running_var.data_ptr()))
+                                 p_x2=bn.running_mean.data_ptr(), p_x3=bn.running_var.data_ptr(), p_x4=_ptr(conv_bias)))
             self.fwd.append(conv_op)
 
     def only_consumer_is_cls1x1(self, idx: int) -> bool:
@@ -330,6 +340,18 @@ class _Lowering:
         # order: 'relu_bn' = bn(relu(conv)) (Conv, model.py:115-116); 'bn_relu' = relu(bn(conv)) (ConvPoolSimple,
         # model.py:175; the strided half of ConvPool, model.py:140-142); 'relu' = relu(conv), no BatchNorm (model.py:138-139)
         order = _conv_order(d)
+        if self.fold and bn is not None:
+            # inference, relu(bn(conv(x))): filter and bias carry the BatchNorm, the epilogue the ReLU; r is the block's final output
+            self.bn_tensors(node, Cout)
+            cst = node.t["consts"]
+            op = L.make_op(L.OP_CONV, L.F_BIAS | L.F_RELU, n=self.N, h=src.H, w=src.W, cin=Cin, cout=Cout, ho=Ho, wo=Wo, stride=s, dil=dil,
+                           inmode=src.load_mode, p_in_c=_ptr(src.consts), p_bias=cst.data_ptr() + 4 * 3 * Cout, p_out=r.data_ptr())
+            node.t["wp"] = self.add_pack(w, Cout, Cin, True, False, wino=self.wants_winograd(op), scale=cst)      # row 0 = scale
+            op.p[L.RCV_P_W] = node.t["wp"].data_ptr()
+            op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
+            self.emit_bn_forward(node, bn, op, Cout, Ho, Wo, conv_bias=b)
+            node.out = Value("plain", r, Cout, Ho, Wo, None, node)
+            return
         flags = (L.F_BIAS if b is not None else 0) | (L.F_RELU if order != "bn_relu" else 0)
         op = L.make_op(L.OP_CONV, flags, n=self.N, h=src.H, w=src.W, cin=Cin, cout=Cout, ho=Ho, wo=Wo, stride=s, dil=dil,
                        inmode=src.load_mode, p_in_c=_ptr(src.consts),
@@ -368,6 +390,24 @@ class _Lowering:
         if Cin != src.C:
             raise L.RcvError("up node %d: input has %d channels, weight expects %d" % (node.idx, src.C, Cin))
         Ho, Wo = 2 * src.H, 2 * src.W
+        skip = self.ref(d["skip"]) if d.get("skip") is not None else None
+        if (self.fold and skip is not None and (skip.C, skip.H, skip.W) == (Cout, Ho, Wo) and skip.kind == "plain" and skip.input_index is None):
+            # inference: relu(bn(convT(x) + b)) + skip in ONE launch -- BatchNorm in filter and bias, ReLU, then the skip tensor (a final
+            # activation itself: its block folded too) as the epilogue's residual.  (Without a skip there is no launch to save: the block's
+            # consumer applies relu(bn(.)) as its load transform, and LabelProp's tail fuses exactly that form into the classifier.)
+            self.bn_tensors(node, Cout)
+            cst = node.t["consts"]
+            node.t["wp"] = self.add_pack(w, Cin, Cout, False, False, merged=self.use_merged(Cout), scale=cst)
+            t = self.eng._alloc(self.plan, self.N, Ho, Wo, Cout)
+            op = L.make_op(L.OP_TCONV, L.F_BIAS | L.F_RELU | L.F_RESID, n=self.N, h=src.H, w=src.W, cin=Cin,
+                           cout=Cout, ho=Ho, wo=Wo, stride=2, dil=1, aux0=int(self.use_merged(Cout)), inmode=src.load_mode,
+                           p_in_c=_ptr(src.consts), p_w=node.t["wp"].data_ptr(), p_bias=cst.data_ptr() + 4 * 3 * Cout, p_out=t.data_ptr(),
+                           p_resid=skip.buf.data_ptr())
+            op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
+            self.emit_bn_forward(node, bn, op, Cout, Ho, Wo, conv_bias=b)
+            node.t["t"] = t
+            node.out = Value("plain", t, Cout, Ho, Wo, None, node)
+            return
         node.t["wp"] = self.add_pack(w, Cin, Cout, False, False, merged=self.use_merged(Cout))
         t = self.eng._alloc(self.plan, self.N, Ho, Wo, Cout)
         self.bn_tensors(node, Cout)
@@ -761,7 +801,7 @@ class _Lowering:
                 marks[-1] = (end, min(marks[-1][1], lo))
         plan.bwd_marks = marks if training else []
 
-        # ---- the pack launch goes first in the forward list ----
+        # ---- head of the forward list: running statistics -> constants (eval), then the pack launch (whose jobs may scale by them) ----
         head = list(self.pre)
         if self.jobs:        # (a graph without 3x3 filters -- a lone 1x1 classifier -- packs nothing)
             table = (L.RcvPackJob * len(self.jobs))(*self.jobs)
@@ -770,7 +810,7 @@ class _Lowering:
             plan.keep.append(dev_table)
             assert C.sizeof(table) == dev_table.numel()
             max_elems = max((4 if j.merged == 1 else 9) * j.rows_pad * j.cols_pad for j in self.jobs)
-            head = [L.make_op(L.OP_PACK, 0, count=len(self.jobs), aux0=max_elems, p_in=dev_table.data_ptr())] + head
+            head += [L.make_op(L.OP_PACK, 0, count=len(self.jobs), aux0=max_elems, p_in=dev_table.data_ptr())]
         for slots in plan.input_slots:
             for i, (is_bwd, k, sl) in enumerate(slots):
                 if not is_bwd:

@@ -465,6 +465,49 @@ def test_labelprop_inference_vs_golden():
         net(_t(kat["x"]).to(DEV))
 
 
+@pytest.mark.parametrize("make,shape", [
+    (lambda: M.LabelProp(5, 32, 0.0), (2, 8, 120, 160)),
+    (lambda: M.LabelProp(3, 32, 0.0), (3, 8, 56, 72)),
+    (lambda: M.PB_FCN(32, 5, 1, False, 0), (2, 3, 128, 160)),
+    (lambda: M.PB_FCN(32, 5, 1, True, 0), (1, 3, 64, 96)),
+])
+def test_inference_batchnorm_folding_matches_the_unfolded_lowering(make, shape, monkeypatch):
+    """engine.EVAL_FOLD_BN: relu(bn(conv(x))) blocks run as relu(conv'(x) + b') in inference (filter scaled while it is packed, skip
+    added in the transposed conv's epilogue).  Same graph lowered without the folding = the load-transform form the goldens pinned
+    in earlier rounds: logits within the 1e-3 bar, and the folding follows the running statistics when they change."""
+    from robocupvision_amd import engine as E
+    torch.manual_seed(77)
+    net = make().to(DEV)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    net.invalidate()
+    net.eval()
+    x = torch.randn(*shape, device=DEV)
+    with torch.no_grad():
+        y_fold = net(x).clone()
+    monkeypatch.setattr(E, "EVAL_FOLD_BN", False)
+    ref_net = make().to(DEV)
+    ref_net.load_state_dict(net.state_dict())
+    ref_net.eval()
+    with torch.no_grad():
+        y_ref = ref_net(x).clone()
+    close(y_fold, y_ref, "folded vs unfolded logits")
+    # the running statistics move (a training epoch in between, or load_state_dict): the next inference call must re-fold
+    monkeypatch.setattr(E, "EVAL_FOLD_BN", True)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.mul_(0.5); m.running_var.mul_(1.5)
+    net.invalidate()
+    ref_net.load_state_dict(net.state_dict())
+    with torch.no_grad():
+        y2, y2_ref = net(x).clone(), ref_net(x).clone()
+    assert not torch.allclose(y2, y_fold, atol=1e-3)
+    close(y2, y2_ref, "folded vs unfolded logits after the statistics moved")
+
+
 @pytest.mark.parametrize("ctor,B,H,W", [
     (dict(noScale=True), 2, 32, 48),                       # 2x3 planes at the bottom of the 5-level net
     (dict(noScale=True), 2, 80, 112),                      # tiles that do not divide the planes

@@ -34,7 +34,7 @@ def test_version_and_error_text():
 def test_struct_layout_matches_header():
     # rcv_op: int32 kind, uint32 flags, int32 i[20], float f[8], void* p[20]
     assert ctypes.sizeof(L.RcvOp) == 4 + 4 + 4 * 20 + 4 * 8 + 8 * 20
-    assert ctypes.sizeof(L.RcvPackJob) == 8 + 8 + 4 * 8
+    assert ctypes.sizeof(L.RcvPackJob) == 8 + 8 + 4 * 8 + 8      # ... + the per-output-channel scale pointer (inference BatchNorm folding)
 
 
 def test_no_cpu_fallback():

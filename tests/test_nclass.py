@@ -304,3 +304,16 @@ def test_gpu_pb_fcn_step_vs_golden(nc_kats, nc_meta, tag, fused):
     _check_after(model.state_dict(), m["param_after_step_sum"], 0.1)
     res2 = pb_step(model, x, t, res["opt"], weights=m["weights"])
     assert abs(res2["loss"] - m["loss_step2"]) <= 2e-3 * abs(m["loss_step2"]), (res2["loss"], m["loss_step2"])
+
+
+def test_inference_lowering_folds_batchnorm_and_skip_adds():
+    """engine.EVAL_FOLD_BN: the inference plans of the relu(bn(conv)) graphs carry no RCV_OP_COMBINE launch (the skip add rides in the
+    transposed conv's epilogue); ROBO_UNet (bn(relu(conv)), nothing to fold) keeps its load-transform form; training plans are untouched."""
+    for model, shape in ((M.LabelProp(5, 32, 0.0), (2, 120, 160, 8)), (M.PB_FCN(32, 5, 1, False, 0), (2, 3, 128, 160))):
+        eng, plan = _lower(model, shape, training=False)
+        labels = plan.fwd.labels(eng.handle)
+        assert not any("combine" in l for l in labels), labels
+    eng, plan = _lower(M.ROBO_UNet(), (2, 3, 48, 64), training=False)
+    assert any("combine" in l for l in plan.fwd.labels(eng.handle))
+    eng, plan = _lower(M.PB_FCN(32, 5, 1, False, 0), (2, 3, 128, 160), training=True)
+    assert any("combine" in l for l in plan.fwd.labels(eng.handle))
