@@ -129,6 +129,10 @@ enum {
                                * logits gradient tensor and RCV_OP_CE_BWD are not needed                                              */
 #define RCV_F_SIDE_STREAM (1u << 16) /* rcv_run: enqueue this op on the handle's side stream (forked from / joined to the caller's
                                       * stream inside the call): ops off the critical path, e.g. the filter gradients of backward */
+#define RCV_F_MFMA_FP32 (1u << 17) /* CONV / TCONV / WGRAD: contract on the fp32 matrix instructions (v_mfma_f32_16x16x4_f32) only.  Without it the
+                                      wide layers form their fp32 products on the bf16 matrix pipe from operands split EXACTLY into three
+                                      bf16 values (six partial products per multiply-add, fp32 accumulate; error <= the fp32 chain's against
+                                      fp64, csrc/wgrad_bf3.hip): same results to fp32 rounding, 2-2.5 x the matrix rate.  Part of the plan key. */
 #define RCV_F_CONCAT    256u  /* COMBINE: out[..,0:C] = relu(t*s+h), out[..,C:2C] = f(r)  (v2 skip concat, model.py:507) */
 /* bits 20..22: profiling ablations of diagnostic builds (skip staging / skip the contraction); the shipped kernels of the wide
  * layers ignore them */

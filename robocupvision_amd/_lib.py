@@ -28,6 +28,7 @@ F_BIAS, F_RELU, F_RESID, F_OUT_NCHW, F_FLIP, F_TRANSPOSED_SRC, F_ARGMAX, F_TRAIN
 F_FUSED_UP = 512
 F_FUSED_CE = 1024
 F_SIDE_STREAM = 1 << 16
+F_MFMA_FP32 = 1 << 17      # contract on the fp32 matrix instructions only (rcv.h RCV_F_MFMA_FP32)
 
 
 class RcvOp(C.Structure):

@@ -89,7 +89,7 @@ static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 static inline std::string rcv_plan_key(const rcv_op* op) {
   int32_t k[1 + RCV_I__N];
-  k[0] = op->kind | (int32_t)((op->flags & RCV_F_RESID) << 16);   // the only flag a planner looks at (conv_first_supported)
+  k[0] = op->kind | (int32_t)((op->flags & RCV_F_RESID) << 16) | (int32_t)((op->flags & RCV_F_MFMA_FP32) << 4);   // the flags a planner looks at
   memcpy(k + 1, op->i, sizeof(op->i));
   k[1 + RCV_I_NPART] = 0; k[1 + RCV_I_NSPLIT] = 0;    // outputs of the planning, not inputs
   return std::string(reinterpret_cast<const char*>(k), sizeof(k));

@@ -63,3 +63,8 @@ static inline int wgrad_cap(int CA) { return CA <= 4 ? 4 : round_up(CA, 16); }
 bool wgrad_first_supported(const rcv_op* op);
 int wgrad_first_nsplit(const rcv_handle* h, const rcv_op* op);
 int wgrad_first_launch(const rcv_handle* h, const WgradArgs& a, hipStream_t s);
+
+// wide stride-1 layers on the bf16 matrix pipe (wgrad_bf3.hip)
+bool wgrad_bf3_supported(const rcv_handle* h, const rcv_op* op);
+void wgrad_bf3_geometry(const rcv_handle* h, const rcv_op* op, int* tw, int* tiles_x, int* tiles_y, int* nsplit, int* nctiles);
+int wgrad_bf3_launch(const rcv_handle* h, const WgradArgs& a, int tw, hipStream_t s);

@@ -534,7 +534,7 @@ static int wlaunch_inst(const WgradArgs& a, bool gtwo, dim3 grid, size_t lds, hi
   return RCV_OK;
 }
 
-struct WPlan { int first; int nctiles; int tile; int R, Wt, Wt4, tiles_x, tiles_y, IH, IW, SP, SG, nsplit, pl_floats, gl_floats; size_t lds; dim3 grid; int CAP, CBP; };
+struct WPlan { int first; int bf3; int nctiles; int tile; int R, Wt, Wt4, tiles_x, tiles_y, IH, IW, SP, SG, nsplit, pl_floats, gl_floats; size_t lds; dim3 grid; int CAP, CBP; };
 
 static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
   const int N = op->i[RCV_I_N], H = op->i[RCV_I_H], W = op->i[RCV_I_W];
@@ -561,6 +561,13 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
     pl->nctiles = 1; pl->lds = 0; pl->grid = dim3(pl->nsplit, 1, 1);
     pl->R = 8; pl->Wt = 64; pl->Wt4 = 64; pl->tiles_x = ceil_div(Wp, 64); pl->tiles_y = ceil_div(Hp, 8);
     pl->IH = 8 + 2 * d; pl->IW = 64 + 2 * d; pl->SP = 8; pl->SG = 1; pl->pl_floats = 0; pl->gl_floats = 0;
+    return RCV_OK;
+  }
+  pl->bf3 = 0;
+  if (wgrad_bf3_supported(h, op)) {     // wide stride-1 layers: fp32 products on the bf16 matrix pipe (wgrad_bf3.hip)
+    wgrad_bf3_geometry(h, op, &pl->bf3, &pl->tiles_x, &pl->tiles_y, &pl->nsplit, &pl->nctiles);
+    pl->lds = 0; pl->grid = dim3(pl->nsplit * pl->nctiles, 1, 1);
+    pl->R = 64 / pl->bf3; pl->Wt = pl->bf3; pl->Wt4 = pl->bf3; pl->IH = pl->R + 2; pl->IW = pl->bf3 + 2; pl->SP = 0; pl->SG = 0; pl->pl_floats = 0; pl->gl_floats = 0;
     return RCV_OK;
   }
   // (an NCHW image with 4 channels does not fit the 2-block folded tile and the 5-block one carries no NCHW path: 16 x 16 tile)
@@ -722,6 +729,13 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     query->part_bytes = (size_t)pl.nsplit * (9 * (size_t)pl.CBP * pl.CAP + pl.CBP) * sizeof(float);
     return RCV_OK;
   }
+  if (query && pl.bf3) {
+    snprintf(query->label, sizeof(query->label), "wgrad_bf3<%d>", pl.bf3);
+    query->n_part = 0;
+    query->n_split = pl.nsplit;
+    query->part_bytes = (size_t)pl.nsplit * (9 * (size_t)pl.CBP * pl.CAP + pl.CBP) * sizeof(float);
+    return RCV_OK;
+  }
   if (query) {
     const WTile& wt = kWT[pl.tile];
     snprintf(query->label, sizeof(query->label), "wgrad_mfma<%d,%d,%d,%d,%d,f%d>", wt.WM, wt.WN, wt.WAVES_M, wt.WAVES_N, wt.WAVES_K, wt.NBF);
@@ -752,6 +766,7 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   RCV_CHECK_ARG(!p_two || a.p_aux, "wgrad: pointwise gradient load needs aux");
   a.part_bias = (op->flags & RCV_F_BIAS) ? a.part + (size_t)pl.nsplit * 9 * pl.CBP * pl.CAP : nullptr;
   if (pl.first) return wgrad_first_launch(h, a, s);
+  if (pl.bf3) return wgrad_bf3_launch(h, a, pl.bf3, s);
   switch (pl.tile) {
     case 0: return wlaunch_inst<2, 2, 2, 2, 1, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
     case 1: return wlaunch_inst<2, 2, 2, 1, 2, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);
