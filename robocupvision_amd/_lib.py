@@ -131,11 +131,15 @@ def join_side(h, stream_ptr: int):
     check(load().rcv_join_side(h, C.c_void_p(stream_ptr)), "rcv_join_side")
 
 
+# RCV_MFMA_FP32=1: every contraction on the fp32 matrix instructions (the A/B switch for the split-bf16 kernels, rcv.h RCV_F_MFMA_FP32)
+MATRIX_FLAGS = F_MFMA_FP32 if os.environ.get("RCV_MFMA_FP32") else 0
+
+
 def make_op(kind: int, flags: int = 0, **kw) -> RcvOp:
     """Build a record; keyword names are the lower-cased slot names (n=, cin=, p_in=, f0=...)."""
     op = RcvOp()
     op.kind = kind
-    op.flags = flags
+    op.flags = flags | (MATRIX_FLAGS if kind in (OP_CONV, OP_TCONV, OP_WGRAD) else 0)
     for k, v in kw.items():
         if k.startswith("p_"):
             idx = globals()["RCV_P_" + k[2:].upper()]

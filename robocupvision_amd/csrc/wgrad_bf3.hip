@@ -55,13 +55,35 @@ __device__ __forceinline__ B3Tri b3_split2(float x0, float x1) {
   return t;
 }
 
-// One operand tile: global -> load transform -> three bf16 planes in LDS.  16 threads share a pixel (one 16-byte channel quad each);
-// a pixel outside the plane (or outside the tile's valid columns) is stored as zero.  SWZ: the P image's swizzle.
-template <int MODE, int NPIX, int TWP, bool SUM, bool SWZ>
-__device__ __forceinline__ void b3_stage(const float* __restrict__ src, const float* __restrict__ aux, const float* __restrict__ consts, char* img,
-                                         int plane_bytes, int pitch, int tid, int ch0, int C, int row0, int oy, int ox, int PH, int PW, float4& sum) {
-  constexpr bool TWO = MODE == RCV_LOAD_GRAD_ENC || MODE == RCV_LOAD_GRAD_DEC;
-  constexpr int UNR = 4, STEP = 16;                   // 256 staging threads: 16 pixels per pass
+// One operand tile: global -> load transform -> three bf16 planes in LDS, in two steps so that the loads of BOTH operand tiles of a pixel
+// tile are in flight before the first is consumed (staged one batch of four after the other, a tile cost three serialized HBM/L2 round
+// trips: 26 us of staging per launch beside 40 us of contraction, and the two did not overlap).  16 threads share a pixel (one 16-byte
+// channel quad each); a pixel outside the plane is stored as zero.
+template <int NPIX, int TWP, bool TWO>
+struct B3Regs {
+  static constexpr int NU = (NPIX + 15) / 16;        // 256 staging threads: 16 pixels per pass
+  float4 x[NU], ax[TWO ? NU : 1];
+  bool ok[NU];
+};
+template <int NPIX, int TWP, bool TWO>
+__device__ __forceinline__ void b3_load(B3Regs<NPIX, TWP, TWO>& r, const float* __restrict__ src, const float* __restrict__ aux, bool two, int tid, int ch0, int C,
+                                        int row0, int oy, int ox, int PH, int PW) {
+  const int q = tid & 15, lp = tid >> 4;
+  const int ch = ch0 + 4 * q;
+#pragma unroll
+  for (int u = 0; u < B3Regs<NPIX, TWP, TWO>::NU; ++u) {
+    const int pix = u * 16 + lp;
+    const int iy = pix / TWP, ix = pix - iy * TWP;                  // (compile-time divisor)
+    r.ok[u] = pix < NPIX && (unsigned)(oy + iy) < (unsigned)PH && (unsigned)(ox + ix) < (unsigned)PW;
+    const uint32_t o = r.ok[u] ? (uint32_t)(((row0 + oy + iy) * PW + ox + ix) * C + ch) : 0u;
+    r.x[u] = wld4(src + o);
+    if (TWO) { if (two) r.ax[u] = wld4(aux + o); }
+  }
+}
+// SWZ: the P image's swizzle.
+template <int MODE, int NPIX, int TWP, bool TWO, bool SUM, bool SWZ>
+__device__ __forceinline__ void b3_store(const B3Regs<NPIX, TWP, TWO>& r, const float* __restrict__ consts, char* img, int plane_bytes, int pitch, int tid,
+                                         int ch0, int C, float4& sum) {
   const int q = tid & 15, lp = tid >> 4;
   const int ch = ch0 + 4 * q;
   float4 k[5];
@@ -70,44 +92,20 @@ __device__ __forceinline__ void b3_stage(const float* __restrict__ src, const fl
     for (int j = 0; j < 5; ++j) k[j] = wld4(consts + (size_t)j * C + ch);
   }
 #pragma unroll
-  for (int pix0 = 0; pix0 < NPIX; pix0 += UNR * STEP) {
-    float4 x[UNR], ax[UNR];
-    bool ok[UNR];
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int pix = pix0 + u * STEP + lp;
-      ok[u] = false;
-      if (pix0 + u * STEP >= NPIX) continue;                           // (compile time: this pass lies past the tile)
-      const int iy = pix / TWP, ix = pix - iy * TWP;                  // (compile-time divisor)
-      ok[u] = pix < NPIX && (unsigned)(oy + iy) < (unsigned)PH && (unsigned)(ox + ix) < (unsigned)PW;
-      const uint32_t o = ok[u] ? (uint32_t)(((row0 + oy + iy) * PW + ox + ix) * C + ch) : 0u;
-      x[u] = wld4(src + o);
-      ax[u] = TWO ? wld4(aux + o) : x[u];
-    }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int pix = pix0 + u * STEP + lp;
-      if (pix0 + u * STEP >= NPIX) continue;                           // (compile time: this pass lies past the tile)
-      float4 v = wxform4<MODE>(x[u], ax[u], k);
-      if (!ok[u]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (SUM) { sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w; }
-      if (pix < NPIX) {
-        const B3Tri a = b3_split2(v.x, v.y), b = b3_split2(v.z, v.w);
-        int off = pix * pitch + 8 * q;
-        if (SWZ) off = pix * pitch + ((((q >> 2) ^ ((pix >> 1) & 3))) << 5) + 8 * (q & 3);
-        *reinterpret_cast<uint2*>(img + off) = make_uint2(a.h, b.h);
-        *reinterpret_cast<uint2*>(img + plane_bytes + off) = make_uint2(a.m, b.m);
-        *reinterpret_cast<uint2*>(img + 2 * plane_bytes + off) = make_uint2(a.l, b.l);
-      }
+  for (int u = 0; u < B3Regs<NPIX, TWP, TWO>::NU; ++u) {
+    const int pix = u * 16 + lp;
+    float4 v = wxform4<MODE>(r.x[u], r.ax[TWO ? u : 0], k);
+    if (!r.ok[u]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SUM) { sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w; }
+    if (pix < NPIX) {
+      const B3Tri a = b3_split2(v.x, v.y), b = b3_split2(v.z, v.w);
+      int off = pix * pitch + 8 * q;
+      if (SWZ) off = pix * pitch + ((((q >> 2) ^ ((pix >> 1) & 3))) << 5) + 8 * (q & 3);
+      *reinterpret_cast<uint2*>(img + off) = make_uint2(a.h, b.h);
+      *reinterpret_cast<uint2*>(img + plane_bytes + off) = make_uint2(a.m, b.m);
+      *reinterpret_cast<uint2*>(img + 2 * plane_bytes + off) = make_uint2(a.l, b.l);
     }
   }
-}
-
-template <int MODE, int TW, bool IS_G>
-__device__ __forceinline__ void b3_stage_mode(const WgradArgs& a, char* buf, int tid, int ch0, int n, int y0, int x0, float4& bsum) {
-  using G = B3Geom<TW>;
-  if (IS_G) b3_stage<MODE, G::GPIX, G::IW, false, false>(a.g, a.g_aux, a.g_c, buf, G::GPLANE, B3_GPITCH, tid, ch0, a.CA, n * a.H, y0 - 1, x0 - 1, a.H, a.W, bsum);
-  else b3_stage<MODE, 64, TW, true, true>(a.p, a.p_aux, a.p_c, buf + 3 * G::GPLANE, B3_PPLANE, B3_PPITCH, tid, ch0, a.CB, n * a.Hp, y0, x0, a.Hp, a.Wp, bsum);
 }
 
 __device__ __forceinline__ bf16x8 b3_read(const lds_char* p, int off0, int off1) {
@@ -141,22 +139,30 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const WgradArgs a) {
     const int n = t / a.tiles_y;
     const int y0 = ty_i * G::TH, x0 = tx_i * TW;
     float4 nosum = make_float4(0.f, 0.f, 0.f, 0.f);
+    // every load of the tile first (GTWO: the gathered operand is the two-tensor one, otherwise the pointwise one may be)
+    B3Regs<G::GPIX, G::IW, GTWO> rg;
+    B3Regs<64, TW, !GTWO> rp;
+    const bool p_two = !GTWO && (a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC);
+    b3_load(rg, a.g, a.g_aux, true, tid, ca0, a.CA, n * a.H, y0 - 1, x0 - 1, a.H, a.W);
+    b3_load(rp, a.p, a.p_aux, p_two, tid, cb0, a.CB, n * a.Hp, y0, x0, a.Hp, a.Wp);
+    char* gi = buf;
+    char* pi = buf + 3 * G::GPLANE;
     if (GTWO) {
-      if (a.g_mode == RCV_LOAD_GRAD_ENC) b3_stage_mode<RCV_LOAD_GRAD_ENC, TW, true>(a, buf, tid, ca0, n, y0, x0, nosum);
-      else b3_stage_mode<RCV_LOAD_GRAD_DEC, TW, true>(a, buf, tid, ca0, n, y0, x0, nosum);
+      if (a.g_mode == RCV_LOAD_GRAD_ENC) b3_store<RCV_LOAD_GRAD_ENC, G::GPIX, G::IW, GTWO, false, false>(rg, a.g_c, gi, G::GPLANE, B3_GPITCH, tid, ca0, a.CA, nosum);
+      else b3_store<RCV_LOAD_GRAD_DEC, G::GPIX, G::IW, GTWO, false, false>(rg, a.g_c, gi, G::GPLANE, B3_GPITCH, tid, ca0, a.CA, nosum);
     } else {
       switch (a.g_mode) {
-        case RCV_LOAD_PLAIN: b3_stage_mode<RCV_LOAD_PLAIN, TW, true>(a, buf, tid, ca0, n, y0, x0, nosum); break;
-        case RCV_LOAD_AFFINE: b3_stage_mode<RCV_LOAD_AFFINE, TW, true>(a, buf, tid, ca0, n, y0, x0, nosum); break;
-        default: b3_stage_mode<RCV_LOAD_AFFINE_RELU, TW, true>(a, buf, tid, ca0, n, y0, x0, nosum); break;
+        case RCV_LOAD_PLAIN: b3_store<RCV_LOAD_PLAIN, G::GPIX, G::IW, GTWO, false, false>(rg, a.g_c, gi, G::GPLANE, B3_GPITCH, tid, ca0, a.CA, nosum); break;
+        case RCV_LOAD_AFFINE: b3_store<RCV_LOAD_AFFINE, G::GPIX, G::IW, GTWO, false, false>(rg, a.g_c, gi, G::GPLANE, B3_GPITCH, tid, ca0, a.CA, nosum); break;
+        default: b3_store<RCV_LOAD_AFFINE_RELU, G::GPIX, G::IW, GTWO, false, false>(rg, a.g_c, gi, G::GPLANE, B3_GPITCH, tid, ca0, a.CA, nosum); break;
       }
     }
-    switch (GTWO && (a.p_mode == RCV_LOAD_GRAD_ENC || a.p_mode == RCV_LOAD_GRAD_DEC) ? RCV_LOAD_PLAIN : a.p_mode) {
-      case RCV_LOAD_PLAIN: b3_stage_mode<RCV_LOAD_PLAIN, TW, false>(a, buf, tid, cb0, n, y0, x0, bsum); break;
-      case RCV_LOAD_AFFINE: b3_stage_mode<RCV_LOAD_AFFINE, TW, false>(a, buf, tid, cb0, n, y0, x0, bsum); break;
-      case RCV_LOAD_AFFINE_RELU: b3_stage_mode<RCV_LOAD_AFFINE_RELU, TW, false>(a, buf, tid, cb0, n, y0, x0, bsum); break;
-      case RCV_LOAD_GRAD_ENC: if (!GTWO) b3_stage_mode<RCV_LOAD_GRAD_ENC, TW, false>(a, buf, tid, cb0, n, y0, x0, bsum); break;
-      default: if (!GTWO) b3_stage_mode<RCV_LOAD_GRAD_DEC, TW, false>(a, buf, tid, cb0, n, y0, x0, bsum); break;
+    switch (a.p_mode) {
+      case RCV_LOAD_PLAIN: b3_store<RCV_LOAD_PLAIN, 64, TW, !GTWO, true, true>(rp, a.p_c, pi, B3_PPLANE, B3_PPITCH, tid, cb0, a.CB, bsum); break;
+      case RCV_LOAD_AFFINE: b3_store<RCV_LOAD_AFFINE, 64, TW, !GTWO, true, true>(rp, a.p_c, pi, B3_PPLANE, B3_PPITCH, tid, cb0, a.CB, bsum); break;
+      case RCV_LOAD_AFFINE_RELU: b3_store<RCV_LOAD_AFFINE_RELU, 64, TW, !GTWO, true, true>(rp, a.p_c, pi, B3_PPLANE, B3_PPITCH, tid, cb0, a.CB, bsum); break;
+      case RCV_LOAD_GRAD_ENC: if constexpr (!GTWO) b3_store<RCV_LOAD_GRAD_ENC, 64, TW, !GTWO, true, true>(rp, a.p_c, pi, B3_PPLANE, B3_PPITCH, tid, cb0, a.CB, bsum); break;
+      default: if constexpr (!GTWO) b3_store<RCV_LOAD_GRAD_DEC, 64, TW, !GTWO, true, true>(rp, a.p_c, pi, B3_PPLANE, B3_PPITCH, tid, cb0, a.CB, bsum); break;
     }
   };
   // bias partial: sum over the staging threads that hold the same channel quad (fixed order)
@@ -173,14 +179,15 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const WgradArgs a) {
       }
     }
   };
+  const bool do_stage = !(a.dbg & RCV_F_DBG_NOSTAGE), do_mfma = !(a.dbg & RCV_F_DBG_NOMFMA);      // (ablation timings: scripts/bench_op.py --flags)
   if (producer) {
     // barrier for barrier the consumer path below: 1 + one per tile (+ the bias partial's)
-    if (split < a.ntiles) stage(split, smem3);
+    if (split < a.ntiles && do_stage) stage(split, smem3);
     __syncthreads();
     int it = 0;
     for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
       const int next = tile + a.nsplit;
-      if (next < a.ntiles) stage(next, smem3 + ((it + 1) & 1) * G::BUF);
+      if (next < a.ntiles && do_stage) stage(next, smem3 + ((it + 1) & 1) * G::BUF);
       __syncthreads();
     }
     bias_partial();
@@ -259,10 +266,11 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const WgradArgs a) {
   {
     int it = 0;
     for (int tile = split; tile < a.ntiles; tile += a.nsplit, ++it) {
-      contract(lds0 + (it & 1) * G::BUF);
+      if (do_mfma) contract(lds0 + (it & 1) * G::BUF);
       __syncthreads();
     }
   }
+  if (!(a.dbg & RCV_F_DBG_NOEPI)) {
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -275,6 +283,7 @@ __global__ __launch_bounds__(512) void wgrad_bf3_kernel(const WgradArgs a) {
           const int ca = ca0 + (wave_n * 2 + nn) * 16 + l15;
           a.part[(((size_t)split * 9 + t) * a.CBP + cb) * a.CAP + ca] = acc[t][m][nn][r];
         }
+  }
   bias_partial();
 }
 
