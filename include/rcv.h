@@ -208,8 +208,10 @@ int rcv_join_side(rcv_handle* h, void* stream);
 int rcv_run_timed(rcv_handle* h, const rcv_op* ops, int n, void* stream, float* ms);
 
 /* Filter layout the library wants for an RCV_OP_CONV record before its filter is packed: 0 = [9 taps][Cin][Cout] (rcv_pack_job.merged
- * 0), 2 = Winograd F(2x2,3x3) transformed [16][Cin][Cout] (rcv_pack_job.merged 2; the record then carries i[RCV_I_AUX0] = 2).  The
- * wide stride-1 layers whose grid covers the chip answer 2; `force` != 0 answers 2 for every shape the Winograd kernel can run. */
+ * 0), 2 = Winograd F(2x2,3x3) transformed [16][Cin][Cout] (rcv_pack_job.merged 2), 3 = split-bf16 [3 planes][9][Cin / 32][Cout][32]
+ * (rcv_pack_job.merged 3, rows padded to 32; 1.5 x the bytes of layout 0); the record then carries the answer in i[RCV_I_AUX0].  The
+ * wide (Cin % 32 == 0, >= 64 channels) stride-1 layers whose grid covers the chip answer 3 -- or 2 when the record carries
+ * RCV_F_MFMA_FP32; `force` != 0 answers 2 for every shape the Winograd kernel can run. */
 int rcv_op_filter_layout(const rcv_handle* h, const rcv_op* op, int force);
 
 /* Label of the kernel (template instantiation / tiling) the library launches for `op`, e.g.
@@ -225,7 +227,9 @@ typedef struct rcv_pack_job {
   int32_t flip;           /* 1: tap t reads source tap 8-t                                        */
   int32_t rows_pad, cols_pad;
   int32_t merged;         /* 1: transposed-conv "merged parity" layout [4 taps (dy,dx)][rows][4*cols] (see conv_mfma.hip);
-                           * 2: Winograd layout [16][rows][cols] = G g G^T (see conv_wino.hip)                                  */
+                           * 2: Winograd layout [16][rows][cols] = G g G^T (see conv_wino.hip);
+                           * 3: split-bf16 layout: every value as three bf16 (v = h + m + l exactly), dst = [plane][9][rows_pad / 32][cols_pad][32]
+                           *    bf16 (rows_pad % 32 == 0; 9 * rows_pad * cols_pad * 6 bytes; see conv_bf3.hip)                   */
   int32_t reserved;
   const float* scale; /* NULL, or one factor per OUTPUT channel (column) applied while packing: inference folds an eval-mode BatchNorm
                        * that follows the conv directly (relu(bn(conv(x))), model.py:175,190-194) into the filter, w'[co] = w[co] * scale[co] */

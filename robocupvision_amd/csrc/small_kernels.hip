@@ -62,7 +62,7 @@ __global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
     }
     return;
   }
-  const int total = (jb.merged ? 4 : 9) * per_tap;
+  const int total = (jb.merged == 1 ? 4 : 9) * per_tap;
   const int rows = jb.rows_from_d1 ? jb.D1 : jb.D0;
   const int cols = jb.rows_from_d1 ? jb.D0 : jb.D1;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
@@ -73,7 +73,7 @@ __global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
     float v = 0.f;
     int ts = jb.flip ? 8 - t : t;
     bool ok = row < rows && col < cols;
-    if (jb.merged) {
+    if (jb.merged == 1) {
       // virtual column = parity*cols + col; tap t = (dy,dx) of the 2x2 input window.
       // output row 2y+py takes input row y+dy through filter row ky: py=0: (dy=0,ky=1); py=1: (dy=0,ky=2),(dy=1,ky=0)
       const int ph = col / cols;
@@ -90,7 +90,21 @@ __global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
       v = jb.src[((size_t)d0 * jb.D1 + d1) * 9 + ts];
       if (jb.scale) v *= jb.scale[col];
     }
-    jb.dst[e] = v;
+    if (jb.merged == 3) {
+      // split-bf16 layout of conv_bf3.hip: v = h + m + l exactly (three round-to-nearest bf16 steps, every remainder exact);
+      // dst = [plane][tap][row / 32][col][row % 32] bf16 -- the eight consecutive input channels a lane of v_mfma_f32_16x16x32_bf16
+      // holds are 16 contiguous bytes
+      __bf16* d16 = reinterpret_cast<__bf16*>(jb.dst);
+      const size_t plane = (size_t)9 * per_tap;
+      const size_t o = (((size_t)t * (jb.rows_pad >> 5) + (row >> 5)) * jb.cols_pad + col) * 32 + (row & 31);
+      const __bf16 hh = (__bf16)v;
+      const float r1 = v - (float)hh;
+      const __bf16 mm = (__bf16)r1;
+      const __bf16 ll = (__bf16)(r1 - (float)mm);
+      d16[o] = hh; d16[plane + o] = mm; d16[2 * plane + o] = ll;
+    } else {
+      jb.dst[e] = v;
+    }
   }
 }
 

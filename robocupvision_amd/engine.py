@@ -259,25 +259,30 @@ class _Lowering:
             return 0
         return v.buf.data_ptr()
 
-    def add_pack(self, param, D0, D1, rows_from_d1, flip, merged=False, wino=False, scale: Optional[torch.Tensor] = None):
+    def add_pack(self, param, D0, D1, rows_from_d1, flip, merged=False, wino=0, scale: Optional[torch.Tensor] = None):
+        """wino: the layout rcv_op_filter_layout asked for (0 plain, 2 Winograd, 3 split-bf16: three bf16 per value, rows padded to 32)."""
+        wino = int(wino)
         rows = D1 if rows_from_d1 else D0
         cols = D0 if rows_from_d1 else D1
-        rp, cp = _round_up(rows, 4), _round_up(cols * (4 if merged else 1), 16)
-        dst = self.eng._zeros(self.plan, (16 if wino else (4 if merged else 9)) * rp * cp)
+        rp, cp = _round_up(rows, 32 if wino == 3 else 4), _round_up(cols * (4 if merged else 1), 16)
+        n_floats = 16 * rp * cp if wino == 2 else ((9 * rp * cp * 3) // 2 if wino == 3 else (4 if merged else 9) * rp * cp)
+        dst = self.eng._zeros(self.plan, n_floats)
         j = L.RcvPackJob()
         j.src, j.dst, j.D0, j.D1 = param.data_ptr(), dst.data_ptr(), D0, D1
         j.rows_from_d1, j.flip, j.rows_pad, j.cols_pad = int(rows_from_d1), int(flip), rp, cp
-        j.merged = 2 if wino else int(merged)
+        j.merged = wino if wino else int(merged)
         j.scale = scale.data_ptr() if scale is not None else None      # per output channel (inference BatchNorm folding)
         self.jobs.append(j)
         return dst
 
-    def wants_winograd(self, op: L.RcvOp) -> bool:
-        """Ask the library whether this conv record should get the Winograd-transformed filter (and mark the record)."""
-        if WINOGRAD == "off" or not L.op_filter_layout(self.eng.handle, op, WINOGRAD == "force"):
-            return False
-        op.i[L.RCV_I_AUX0] = 2
-        return True
+    def wants_winograd(self, op: L.RcvOp) -> int:
+        """Ask the library which filter layout this conv record should get (0 plain, 2 Winograd, 3 split-bf16) and mark the record."""
+        if WINOGRAD == "off":
+            return 0
+        layout = L.op_filter_layout(self.eng.handle, op, WINOGRAD == "force")
+        if layout:
+            op.i[L.RCV_I_AUX0] = layout
+        return layout
 
     def side(self, op: L.RcvOp, input_slot: Optional[tuple] = None):
         """A filter-gradient-side op of the node being lowered (filter gradient, its reduction, a bias memset).  ``input_slot`` =

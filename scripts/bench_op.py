@@ -22,7 +22,7 @@ ap.add_argument("--mode", default="affine"); ap.add_argument("--mode2", default=
 ap.add_argument("--stats", default="none"); ap.add_argument("--merged", type=int, default=0)
 ap.add_argument("--resid", type=int, default=0); ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--flags", type=int, default=0)
-ap.add_argument("--wino", type=int, default=0, help="1: Winograd kernel (filter buffer in the transformed layout, i[AUX0] = 2)")
+ap.add_argument("--wino", type=int, default=0, help="1 or 2: Winograd kernel (filter buffer in the transformed layout, i[AUX0] = 2); 3: split-bf16 kernel (i[AUX0] = 3)")
 ap.add_argument("--stamps", type=int, default=0, help="diagnostic library build (make STAMPS=1): print the per-segment cycle shares of conv_dma_kernel")
 a = ap.parse_args()
 dev = torch.device("cuda:0"); h = L.handle(0)
@@ -41,13 +41,15 @@ if a.kind in ("conv", "tconv"):
     aux = rnd(N, H, W, Cin).abs()
     consts = torch.rand(5, Cin, generator=g).to(dev) + 0.5
     taps = 16 if a.wino else (4 if a.merged else 9)
-    wp = rnd(taps * r4(Cin) * r16(Cout * (4 if a.merged else 1)))
+    wp = rnd(taps * r4(Cin) * r16(Cout * (4 if a.merged else 1))) * 0.1
+    if a.wino == 3:      # three bf16 planes: any finite bf16 pattern will do for a timing
+        wp = (torch.randn(taps * r4(Cin) * r16(Cout) * 2, generator=g) * 0.1).to(torch.bfloat16).to(dev).view(torch.float32)
     out = torch.empty(N, Ho, Wo, Cout, device=dev)
     ea = rnd(N, Ho, Wo, Cout); resid = rnd(N, Ho, Wo, Cout); ec = torch.rand(5, Cout, generator=g).to(dev)
     bias = rnd(Cout)
     op = L.make_op(L.OP_TCONV if a.kind == "tconv" else L.OP_CONV, flags | L.F_BIAS | (L.F_RESID if a.resid else 0), n=N, h=H, w=W,
                    cin=Cin, cout=Cout, ho=Ho, wo=Wo, stride=(2 if a.kind == "tconv" else s), dil=d, inmode=MODES[a.mode], stats=STATS[a.stats],
-                   aux0=(2 if a.wino else a.merged), p_in=x.data_ptr(), p_in_aux=aux.data_ptr(), p_in_c=consts.data_ptr(), p_w=wp.data_ptr(), p_bias=bias.data_ptr(),
+                   aux0=((2 if a.wino == 1 else a.wino) if a.wino else a.merged), p_in=x.data_ptr(), p_in_aux=aux.data_ptr(), p_in_c=consts.data_ptr(), p_w=wp.data_ptr(), p_bias=bias.data_ptr(),
                    p_out=out.data_ptr(), p_resid=resid.data_ptr(), p_epi_aux=ea.data_ptr(), p_epi_c=ec.data_ptr())
     two = a.mode in ("grad_enc", "grad_dec")
     npix_out = N * (H * W if a.kind == "tconv" else Ho * Wo)

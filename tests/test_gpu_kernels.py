@@ -50,26 +50,29 @@ def test_conv_kernels_vs_fp64(N, H, W, Cin, Cout, s, mode_name):
     w, resid = _rand(gen, Cout, Cin, 3, 3, scale=0.1), _rand(gen, N, Ho, Wo, Cout)
     ref = F.conv2d(_load_fp64(mode, x, xa, c, L).permute(0, 3, 1, 2), w.double(), stride=s, padding=1).permute(0, 2, 3, 1) + resid.double()
     xd, xad, cd, wd, rd = (v.to(DEV) for v in (x, xa, c, w, resid))
-    winos = [0] + ([1] if (s == 1 and Cin % 16 == 0 and Cin >= 32 and Cout >= 64) else [])
+    # filter layouts (rcv_op_filter_layout): 0 plain, 2 Winograd, 3 split-bf16 (conv_bf3.hip: fp32 products as six bf16 MFMA products)
+    winos = [0] + ([2] if (s == 1 and Cin % 16 == 0 and Cin >= 32 and Cout >= 64) else []) + \
+            ([3] if (s == 1 and Cin % 32 == 0 and Cin >= 64 and Cout >= 64) else [])
     for wino in winos:
-        rp, cp = (Cin + 3) // 4 * 4, (Cout + 15) // 16 * 16
+        rp, cp = (Cin + (31 if wino == 3 else 3)) // (32 if wino == 3 else 4) * (32 if wino == 3 else 4), (Cout + 15) // 16 * 16
         wp = torch.zeros((16 if wino else 9) * rp * cp, device=DEV)
         job = L.RcvPackJob()
         job.src, job.dst, job.D0, job.D1 = wd.data_ptr(), wp.data_ptr(), Cout, Cin
-        job.rows_from_d1, job.flip, job.rows_pad, job.cols_pad, job.merged = 1, 0, rp, cp, 2 if wino else 0
+        job.rows_from_d1, job.flip, job.rows_pad, job.cols_pad, job.merged = 1, 0, rp, cp, wino
         table = torch.frombuffer(bytearray(bytes((L.RcvPackJob * 1)(job))), dtype=torch.uint8).to(DEV)
         out = torch.full((N, Ho, Wo, Cout), float("nan"), device=DEV)
         pack = L.make_op(L.OP_PACK, 0, count=1, aux0=16 * rp * cp, p_in=table.data_ptr())
         conv = L.make_op(L.OP_CONV, L.F_RESID, n=N, h=H, w=W, cin=Cin, cout=Cout, ho=Ho, wo=Wo, stride=s, dil=1, inmode=mode,
-                         aux0=2 if wino else 0, p_in=xd.data_ptr(), p_in_aux=xad.data_ptr(), p_in_c=cd.data_ptr(), p_w=wp.data_ptr(),
+                         aux0=wino, p_in=xd.data_ptr(), p_in_aux=xad.data_ptr(), p_in_c=cd.data_ptr(), p_w=wp.data_ptr(),
                          p_out=out.data_ptr(), p_resid=rd.data_ptr())
         lst = L.OpList([pack, conv])
         label = lst.labels(h)[1]
-        assert label.startswith("conv_wino") == bool(wino), label
+        assert label.startswith("conv_wino") == (wino == 2) and label.startswith("conv_bf3") == (wino == 3), label
         lst.run(h, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
-        assert err <= (2e-6 if wino else 3e-6), (label, err)
+        print(".%s %s: max error %.3e" % (label, (N, H, W, Cin, Cout), err))
+        assert err <= (2e-6 if wino == 2 else 3e-6), (label, err)
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,s,d", [(2, 48, 64, 3, 8, 1, 1), (2, 120, 160, 3, 16, 1, 1), (3, 37, 53, 4, 16, 1, 1), (2, 48, 64, 3, 16, 2, 1),
