@@ -36,6 +36,14 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
+# Split-bf16 kernels (conv_bf3 / wgrad_bf3: every fp32 multiply-add = six v_mfma_f32_16x16x32_bf16 products of operands split exactly into
+# three bf16 values): their matrix-pipe ceiling in ALGORITHMIC fp32 FLOPs is the dense bf16 peak / 6
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_SPLIT_BF16_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+
+
+def mfma_peak(label: str) -> float:
+    return PEAK_SPLIT_BF16_TFLOPS if "_bf3" in label else PEAK_FP32_MFMA_TFLOPS
 
 WORKLOADS = {
     # name: (ctor kwargs, B per GPU, H, W)
@@ -172,17 +180,19 @@ def roofline_block(rows, ms_per_step, workload, batch_override, breakdown):
         a = by.setdefault(r["label"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
         a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
     total_ms = sum(a["ms"] for a in by.values())
-    bound_ms = lambda fl, by_: max(fl / (PEAK_FP32_MFMA_TFLOPS * 1e9), by_ / (PEAK_HBM_GBS * 1e6))
-    t_roof = sum(bound_ms(r["flops"], r["bytes"]) for r in rows)
+    bound_ms = lambda fl, by_, label="": max(fl / (mfma_peak(label) * 1e9), by_ / (PEAK_HBM_GBS * 1e6))
+    t_roof = sum(bound_ms(r["flops"], r["bytes"], r["label"]) for r in rows)
+    t_roof_fp32 = sum(bound_ms(r["flops"], r["bytes"]) for r in rows)      # every contraction priced on the fp32 matrix instruction (rounds 1-2)
     dom = max(by, key=lambda k: by[k]["ms"])
     d = by[dom]
-    mfma_bound = d["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12) >= d["bytes"] / (PEAK_HBM_GBS * 1e9)
+    dom_peak = mfma_peak(dom)
+    mfma_bound = d["flops"] / (dom_peak * 1e12) >= d["bytes"] / (PEAK_HBM_GBS * 1e9)
     tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
     gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
     out = {"bound": "mfma" if mfma_bound else "hbm", "kernel": dom,
-           "achieved": round(tf if mfma_bound else gbs, 3), "peak": PEAK_FP32_MFMA_TFLOPS if mfma_bound else PEAK_HBM_GBS,
+           "achieved": round(tf if mfma_bound else gbs, 3), "peak": round(dom_peak, 1) if mfma_bound else PEAK_HBM_GBS,
            "unit": "TFLOP/s" if mfma_bound else "GB/s",
-           "frac": round((tf / PEAK_FP32_MFMA_TFLOPS) if mfma_bound else (gbs / PEAK_HBM_GBS), 4), "traffic": None,
+           "frac": round((tf / dom_peak) if mfma_bound else (gbs / PEAK_HBM_GBS), 4), "traffic": None,
            "launches_per_step": d["launches"], "avg_launch_ms": round(d["ms"] / d["launches"], 4),
            "share_of_kernel_time": round(d["ms"] / total_ms, 4),
            "algorithmic_tflops": round(tf, 3), "algorithmic_gbs": round(gbs, 1),
@@ -196,6 +206,11 @@ def roofline_block(rows, ms_per_step, workload, batch_override, breakdown):
         out["flop_pricing"] += "; conv_wino executes 16/36 of them on the matrix pipe"
         out["executed_tflops"] = round(tf * 16.0 / 36.0, 3)
         out["mfma_pipe_frac"] = round(tf * 16.0 / 36.0 / PEAK_FP32_MFMA_TFLOPS, 4)
+    elif "_bf3" in dom:
+        out["flop_pricing"] += ("; split-bf16 kernel: six bf16 MFMA products per fp32 multiply-add, peak = %.0f / 6 TFLOP/s of the dense bf16 pipe; "
+                                "%.3f of the fp32 matrix-instruction peak" % (PEAK_BF16_MFMA_TFLOPS, tf / PEAK_FP32_MFMA_TFLOPS))
+        out["executed_tflops"] = round(tf * 6.0, 3)
+        out["mfma_pipe_frac"] = round(tf * 6.0 / PEAK_BF16_MFMA_TFLOPS, 4)
     elif mfma_bound:
         out["executed_tflops"] = round(tf, 3)
         out["mfma_pipe_frac"] = out["frac"]
@@ -204,13 +219,13 @@ def roofline_block(rows, ms_per_step, workload, batch_override, breakdown):
     for r in rows:
         a = fam.setdefault(kernel_family(r["label"]), {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "roof_ms": 0.0})
         a["ms"] += r["ms"]; a["flops"] += r["flops"]; a["bytes"] += r["bytes"]; a["launches"] += 1
-        a["roof_ms"] += bound_ms(r["flops"], r["bytes"])
+        a["roof_ms"] += bound_ms(r["flops"], r["bytes"], r["label"])
     top = []
     for k in sorted(fam, key=lambda k: -fam[k]["ms"])[:8]:
         a = fam[k]
         if a["ms"] <= 0:
             continue
-        fb = a["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12) >= a["bytes"] / (PEAK_HBM_GBS * 1e9)
+        fb = a["flops"] / (mfma_peak(k) * 1e12) >= a["bytes"] / (PEAK_HBM_GBS * 1e9)
         top.append({"kernel": k, "launches_per_step": a["launches"], "ms_per_step": round(a["ms"], 4), "share": round(a["ms"] / total_ms, 4),
                     "bound": "mfma" if fb else "hbm", "frac_of_own_roof": round(a["roof_ms"] / a["ms"], 4),
                     "algorithmic_tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2),
@@ -222,6 +237,9 @@ def roofline_block(rows, ms_per_step, workload, batch_override, breakdown):
         out["traffic_source"] = "profiles/" + src
     out["t_roof_ms"] = round(t_roof, 4)
     out["step_frac"] = round(t_roof / ms_per_step, 4) if ms_per_step > 0 else None
+    # the same sum with EVERY contraction priced at the fp32 matrix-instruction peak (157.3 TFLOP/s): the figure rounds 1-2 reported
+    out["t_roof_fp32_mfma_ms"] = round(t_roof_fp32, 4)
+    out["step_frac_fp32_mfma"] = round(t_roof_fp32 / ms_per_step, 4) if ms_per_step > 0 else None
     out["step_tflops"] = round(sum(a["flops"] for a in by.values()) / (ms_per_step * 1e-3) / 1e12, 3)
     out["step_hbm_gbs_algorithmic"] = round(sum(a["bytes"] for a in by.values()) / (ms_per_step * 1e-3) / 1e9, 1)
     out["sum_kernel_ms"] = round(total_ms, 4)
@@ -230,13 +248,13 @@ def roofline_block(rows, ms_per_step, workload, batch_override, breakdown):
             a = by[k]
             tfk = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0
             gb = a["bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0
-            lb = sum(bound_ms(r["flops"], r["bytes"]) for r in rows if r["label"] == k)
+            lb = sum(bound_ms(r["flops"], r["bytes"], r["label"]) for r in rows if r["label"] == k)
             print("%-28s launches %3d  ms %8.3f  %5.1f%%  %7.2f TF/s  %8.1f GB/s  of its roof %5.2f" %
                   (k, a["launches"], a["ms"], 100 * a["ms"] / total_ms, tfk, gb, lb / a["ms"] if a["ms"] > 0 else 0), file=sys.stderr)
         if os.environ.get("RCV_BENCH_ROWS"):
             # per op: measured vs the per-op roofline bound max(FLOP/157.3T, bytes/8T); sorted by the gap
-            for r in sorted(rows, key=lambda r: -(r["ms"] - bound_ms(r["flops"], r["bytes"]))):
-                lb = bound_ms(r["flops"], r["bytes"])
+            for r in sorted(rows, key=lambda r: -(r["ms"] - bound_ms(r["flops"], r["bytes"], r["label"]))):
+                lb = bound_ms(r["flops"], r["bytes"], r["label"])
                 print("%s %-26s %-24s ms %7.4f  bound %7.4f  gap %7.4f  %6.2f TF/s %7.1f GB/s" %
                       ("B" if r["bwd"] else "F", r["label"], r["shape"], r["ms"], lb, r["ms"] - lb, r["flops"] / max(r["ms"], 1e-9) / 1e9,
                        r["bytes"] / max(r["ms"], 1e-9) / 1e6), file=sys.stderr)
@@ -455,7 +473,13 @@ def main():
         "config": {"workload": args.workload, "per_gpu_batch": B, "global_batch": B * world, "height": H, "width": W,
                    "step": "fwd+CE/argmax+bwd+L1+Adam (train.py:43-74)", "parallelism": "dp%d" % world,
                    "launch": "one captured hipGraph per step" if use_graph else "eager (one rcv_run per pass)",
-                   "loss_after": round(metrics["loss"], 6)},
+                   "loss_after": round(metrics["loss"], 6),
+                   # f32 tensors, f32 accumulation everywhere.  The wide (>= 64-channel) stride-1 layers form their fp32 products from
+                   # operands split EXACTLY into three bf16 values, six bf16 MFMA products per multiply-add (error against fp64 <= the fp32
+                   # MFMA chain's: scripts/micro/split_mfma.hip, tests/test_gpu_kernels.py); RCV_MFMA_FP32=1 runs every contraction on
+                   # v_mfma_f32_16x16x4_f32 instead
+                   "matrix_arithmetic": "fp32 matrix instructions only (RCV_MFMA_FP32=1)" if os.environ.get("RCV_MFMA_FP32")
+                   else "fp32; wide stride-1 layers as exact 3 x bf16 operand splits, 6 bf16 MFMA products per multiply-add, fp32 accumulate"},
     }
 
     eng = model._get_engine()

@@ -100,7 +100,7 @@ struct ConvPlan {
   int first;             // 1: conv_first.hip (3 -> 8 channel first layer on the vector ALU)
   int dev;               // device of the handle the plan belongs to (per-device kernel attributes)
   int wino;              // 1: conv_wino.hip (Winograd F(2x2,3x3) for the wide stride-1 layers)
-  int bf3;               // 1: conv_bf3.hip (wide stride-1 layers: fp32 products on the bf16 matrix pipe, filter in the split layout)
+  int bf3;               // 1: conv_bf3.hip (wide stride-1 layers: fp32 products on the bf16 matrix pipe, filter in the split layout); 2: convn_bf3.hip (narrow layers)
   int small;             // 1: conv_small.hip (inference on planes of a few hundred pixels: one MFMA block per workgroup, K split over its waves)
 };
 
@@ -129,6 +129,12 @@ bool conv_bf3_wanted(const rcv_handle* h, const rcv_op* op);
 bool conv_bf3_supported(const rcv_handle* h, const rcv_op* op, int kind);
 int conv_bf3_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl);
 int conv_bf3_launch(const ConvPlan& pl, const ConvArgs& a, hipStream_t s);
+
+// split-bf16 narrow-layer kernel (convn_bf3.hip)
+bool convn_bf3_wanted(const rcv_handle* h, const rcv_op* op);
+bool convn_bf3_supported(const rcv_handle* h, const rcv_op* op, int kind);
+int convn_bf3_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* pl);
+int convn_bf3_launch(const ConvPlan& pl, const ConvArgs& a, hipStream_t s);
 
 // tiny-plane inference kernel (conv_small.hip)
 bool conv_small_supported(const rcv_handle* h, const rcv_op* op, int kind);

@@ -5,18 +5,14 @@
 
 // Epilogue shared by the conv kernels: bias / ReLU / skip-gradient add, 16-byte NHWC stores, and the per-tile
 // BatchNorm partial sums (forward or backward), reduced in a fixed order through `red` ([WAVES_N][2][COT]).
+// Two parts, so that a persistent kernel can keep the statistics of all its tiles in registers and reduce them once:
+//   conv_epilogue_tile : bias / ReLU / residual, stores, and the lane's share of the BatchNorm sums ADDED to s1 / s2;
+//   conv_epilogue_stats: the fixed-order reduction of s1 / s2 over the workgroup and the partial row `row` of a.part.
 template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND, int EB = (WM == 1 ? WN : 0)>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const TileInfo& ti, f32x4 (&acc)[WM][WN], float* red, int tid) {
-  constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int COT = WM * WAVES_M * 16;
+__device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& a, const TileInfo& ti, f32x4 (&acc)[WM][WN], float (&s1)[WM][4], float (&s2)[WM][4], int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
   const int l15 = lane & 15, l4 = lane >> 4;
-    float s1[WM][4], s2[WM][4];
-#pragma unroll
-    for (int m = 0; m < WM; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[m][r] = 0.f; s2[m][r] = 0.f; }
 #pragma unroll
     for (int m = 0; m < WM; ++m) {
       const int cov = ti.co0 + (wave_m * WM + m) * 16 + 4 * l4;     // (virtual) output channel of this lane
@@ -142,7 +138,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const TileInfo&
         }
       }
     }
-    if (a.stats != RCV_STATS_NONE) {
+}
+
+template <int WM, int WAVES_M, int WAVES_N, int KIND>
+__device__ __forceinline__ void conv_epilogue_stats(const ConvArgs& a, size_t row, int co0, float (&s1)[WM][4], float (&s2)[WM][4], float* red, int tid) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int COT = WM * WAVES_M * 16;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int l15 = lane & 15, l4 = lane >> 4;
+    {
       // wave: sum over the 16 pixel lanes (xor 1,2,4,8 stays inside a 16-lane group); fixed order
 #pragma unroll
       for (int m = 0; m < WM; ++m)
@@ -164,7 +169,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const TileInfo&
           }
       }
       __syncthreads();
-      const size_t row = (size_t)(KIND == KIND_TPHASE ? (ti.py * 2 + ti.px) * a.n_pix_tiles : 0) + ti.pt;
       if (KIND == KIND_TMERGED) {
         // real channel = virtual channel mod Cout: sum the (up to) four parity groups in fixed order
         for (int e = tid; e < 2 * a.Cout; e += NT) {
@@ -179,7 +183,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const TileInfo&
       } else {
         for (int e = tid; e < 2 * COT; e += NT) {
           const int which = e / COT, cl_ = e % COT;
-          const int co = ti.co0 + cl_;
+          const int co = co0 + cl_;
           if (co < a.Cout) {
             float u = 0.f;
 #pragma unroll
@@ -191,3 +195,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const TileInfo&
   }
 }
 
+template <int WM, int WN, int WAVES_M, int WAVES_N, int KIND, int EB = (WM == 1 ? WN : 0)>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, const TileInfo& ti, f32x4 (&acc)[WM][WN], float* red, int tid) {
+  float s1[WM][4], s2[WM][4];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[m][r] = 0.f; s2[m][r] = 0.f; }
+  conv_epilogue_tile<WM, WN, WAVES_M, WAVES_N, KIND, EB>(a, ti, acc, s1, s2, tid);
+  if (a.stats != RCV_STATS_NONE) {
+    const size_t row = (size_t)(KIND == KIND_TPHASE ? (ti.py * 2 + ti.px) * a.n_pix_tiles : 0) + ti.pt;
+    conv_epilogue_stats<WM, WAVES_M, WAVES_N, KIND>(a, row, ti.co0, s1, s2, red, tid);
+  }
+}

@@ -707,7 +707,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   else RCV_CHECK_ARG(Cin % 4 == 0, "conv: Cin=%d must be a multiple of 4 for NHWC operands", Cin);
   if (transposed) {
     RCV_CHECK_ARG(Ho == 2 * H && Wo == 2 * W, "tconv: output must be 2x input (%dx%d -> %dx%d)", H, W, Ho, Wo);
-    pl->kind = op->i[RCV_I_AUX0] ? KIND_TMERGED : KIND_TPHASE;     // AUX0 = 1: filter is packed in the merged layout
+    pl->kind = op->i[RCV_I_AUX0] ? KIND_TMERGED : KIND_TPHASE;     // AUX0 = 1 (or 4: split-bf16): filter is packed in the merged layout
     RCV_CHECK_ARG(pl->kind == KIND_TPHASE || 4 * Cout <= 128, "tconv: merged layout needs Cout <= 32 (got %d)", Cout);
   } else {
     RCV_CHECK_ARG((s == 1 || s == 2) && (d == 1 || d == 2), "conv: stride %d dilation %d unsupported", s, d);
@@ -721,8 +721,9 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   pl->wino = 0;
   pl->small = 0;
   pl->bf3 = 0;
+  if (convn_bf3_supported(h, op, pl->kind)) return convn_bf3_plan(h, op, pl->kind, pl);
   if (conv_bf3_supported(h, op, pl->kind)) return conv_bf3_plan(h, op, pl);
-  RCV_CHECK_ARG(op->i[RCV_I_AUX0] != 3, "conv: a filter packed in the split-bf16 layout needs a stride-1 / dilation-1 conv record");
+  RCV_CHECK_ARG(op->i[RCV_I_AUX0] != 3 && op->i[RCV_I_AUX0] != 4, "conv: a filter packed in a split-bf16 layout needs a record one of the split-bf16 kernels runs");
   if (conv_wino_supported(h, op, pl->kind)) return conv_wino_plan(h, op, pl);
   RCV_CHECK_ARG(transposed || op->i[RCV_I_AUX0] != 2, "conv: a filter packed in the Winograd layout needs stride 1 / dilation 1");
   if (conv_first_supported(op, pl->kind)) return conv_first_plan(h, op, pl);
@@ -850,10 +851,12 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   }
   const int Cout = op->i[RCV_I_COUT];
   const int n_pix_tiles = op->i[RCV_I_N] * pl.tiles_x * pl.tiles_y;
-  const int n_part = (pl.narrow || pl.first) ? pl.grid : n_pix_tiles * pl.n_phases;
+  const int n_part = (pl.narrow || pl.first || pl.bf3 == 2) ? pl.grid : n_pix_tiles * pl.n_phases;
   if (query) {
     static const char* kn[] = {"conv", "tconv", "tconvm", "tconva"};
-    if (pl.bf3) {
+    if (pl.bf3 == 2) {
+      snprintf(query->label, sizeof(query->label), "%sn_bf3<%d,%d,%d>", pl.kind == KIND_TMERGED ? "tconv" : "conv", pl.CK, pl.WM, pl.WN);
+    } else if (pl.bf3) {
       snprintf(query->label, sizeof(query->label), "conv_bf3<64,%d>", 32 * pl.WN);
     } else if (pl.wino) {
       snprintf(query->label, sizeof(query->label), "conv_wino<64,%d>", 16 * pl.WN);
@@ -909,6 +912,7 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
   RCV_CHECK_ARG(a.stats == RCV_STATS_NONE || op->i[RCV_I_NPART] == n_part, "conv: workspace rows %d != %d", op->i[RCV_I_NPART], n_part);
   RCV_CHECK_ARG(!(a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC) || a.epi_aux, "conv: backward statistics need epi_aux");
   RCV_CHECK_ARG(!(a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC) || a.epi_c, "conv: backward statistics need epi_c (scale, shift, mean)");
+  if (pl.bf3 == 2) return convn_bf3_launch(pl, a, s);
   if (pl.bf3) return conv_bf3_launch(pl, a, s);
   if (pl.wino) return conv_wino_launch(pl, a, s);
   if (pl.first) return conv_first_launch(pl, a, s);

@@ -1,0 +1,344 @@
+// Narrow-layer (8 / 16 / 32 input channels) 3x3 convolutions with fp32 products formed on the bf16 matrix pipe.
+//
+// On the fp32 matrix instruction even the 8..32-channel layers of the step are matrix-pipe bound: 16 -> 16 at 32 x 240 x 320 moves 315 MB
+// (52 us at 6 TB/s) but needs 72 us of v_mfma_f32_16x16x4_f32 at peak -- the fp32 kernel (convs_mfma.hip) measured 117 us with its matrix
+// pipe 71 % busy.  With every operand split exactly into three bf16 values and six v_mfma_f32_16x16x32_bf16 products per multiply-add
+// (wgrad_bf3.hip has the arithmetic and its error against fp64) the same contraction is 2.0-2.5 x cheaper and these layers become what
+// their shapes say they are: HBM streams.
+//
+// Roles (those of convs_mfma.hip):  KIND_GATHER   conv / data gradient, stride 1 | 2, dilation 1;
+//                                   KIND_TMERGED  stride-2 transposed conv as a 2 x 2-tap gather with 4 * Cout virtual output channels.
+// GEMM:  D[cov][pixel] += W[cov][k] * X[k][pixel],  k = tap * CIN + ci flattened, 32 k per MFMA: with 8 input channels one MFMA covers
+//   four taps, with 32 one tap.  Lane (i, g) holds k = 32 ks + 8 g .. + 7 = eight consecutive channels of ONE tap:
+//   A = filter, split when packed (RCV_OP_PACK layouts 3 / 4: [plane][k-step][cov][32 k] bf16, zero beyond the last tap), copied once per
+//       persistent workgroup into LDS; lane (cov, g) reads 16 bytes;
+//   B = input tile in LDS as [pixel][plane h|m|l][CIN] bf16; lane (pixel, g) reads the 16 bytes at
+//       pixel record + tap shift(ks, g) + channel offset(ks, g): one per-lane offset per k-step, computed once.
+// Workgroup: persistent over pixel tiles of 64 * WN slots (all output channels); four producer waves stage tile i + 1 (global -> load
+// transform -> split -> LDS) while four consumer waves contract tile i and run the epilogue of conv_mfma.hip (bias / ReLU / residual,
+// 16-byte NHWC stores, BatchNorm sums kept in registers across tiles: one partial row per workgroup).
+#include <type_traits>
+#include "conv_common.h"
+#include "conv_epilogue.h"
+
+typedef __bf16 n3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 n3_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int N3_NU = 11;                 // staging passes: tiles with halo up to 11 * (256 / (CIN / 4)) pixels
+
+__device__ __forceinline__ uint32_t n3_pack(float a, float b) {
+  const n3_bf16x2 v = {(__bf16)a, (__bf16)b};            // v_cvt_pk_bf16_f32 (round to nearest even)
+  return __builtin_bit_cast(uint32_t, v);
+}
+struct N3Tri { uint32_t h, m, l; };
+__device__ __forceinline__ N3Tri n3_split2(float x0, float x1) {
+  N3Tri t;
+  t.h = n3_pack(x0, x1);
+  const float r0 = x0 - __uint_as_float(t.h << 16), r1 = x1 - __uint_as_float(t.h & 0xffff0000u);       // exact
+  t.m = n3_pack(r0, r1);
+  const float s0 = r0 - __uint_as_float(t.m << 16), s1 = r1 - __uint_as_float(t.m & 0xffff0000u);       // exact
+  t.l = n3_pack(s0, s1);
+  return t;
+}
+
+template <bool TWO>
+struct N3Regs {
+  float4 x[N3_NU], ax[TWO ? N3_NU : 1];
+  bool ok[N3_NU];
+};
+
+template <int CIN, bool TWO>
+__device__ __forceinline__ void n3_load(N3Regs<TWO>& r, const ConvArgs& a, const TileInfo& ti, int tid, int npix) {
+  constexpr int Q = CIN / 4, PP = 256 / Q;
+  const int q = tid % Q, lp = tid / Q;
+#pragma unroll
+  for (int u = 0; u < N3_NU; ++u) {
+    const int pix = u * PP + lp;
+    const int iy = fd_div(pix, a.fdIW), ix = pix - iy * a.IW;
+    const int gy = ti.oy0 + iy, gx = ti.ox0 + ix;
+    r.ok[u] = pix < npix && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+    const uint32_t o = r.ok[u] ? (uint32_t)(((ti.n * a.H + gy) * a.W + gx) * CIN + 4 * q) : 0u;
+    r.x[u] = ld4(a.in + o);
+    if (TWO) r.ax[u] = ld4(a.in_aux + o);
+  }
+}
+template <int MODE, int CIN, bool TWO>
+__device__ __forceinline__ void n3_store(const N3Regs<TWO>& r, const ConvArgs& a, char* img, int tid, int npix) {
+  constexpr int Q = CIN / 4, PP = 256 / Q, PITCH = 6 * CIN;
+  const int q = tid % Q, lp = tid / Q;
+  float4 k[5];
+  if (MODE != RCV_LOAD_PLAIN) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) k[j] = ld4(a.in_c + j * CIN + 4 * q);
+  }
+#pragma unroll
+  for (int u = 0; u < N3_NU; ++u) {
+    const int pix = u * PP + lp;
+    float4 v = xform4<MODE>(r.x[u], r.ax[TWO ? u : 0], k);
+    if (!r.ok[u]) v = make_float4(0.f, 0.f, 0.f, 0.f);          // zero padding AFTER the transform
+    if (pix < npix) {
+      const N3Tri lo = n3_split2(v.x, v.y), hi = n3_split2(v.z, v.w);
+      char* d = img + pix * PITCH + 8 * q;
+      *reinterpret_cast<uint2*>(d) = make_uint2(lo.h, hi.h);
+      *reinterpret_cast<uint2*>(d + 2 * CIN) = make_uint2(lo.m, hi.m);
+      *reinterpret_cast<uint2*>(d + 4 * CIN) = make_uint2(lo.l, hi.l);
+    }
+  }
+}
+
+template <int CIN, int WM, int WN, int KIND, bool TWO>
+__global__ __launch_bounds__(512) void convn_bf3_kernel(const ConvArgs a) {
+  constexpr int TAPS = KIND == KIND_GATHER ? 9 : 4;
+  constexpr int NKS = (TAPS * CIN + 31) / 32;
+  constexpr int COT = 16 * WM;
+  constexpr int PITCH = 6 * CIN;
+  constexpr int WPLANE = NKS * COT * 64;                    // bytes of one filter plane
+  constexpr int WBYTES = 3 * WPLANE;
+  extern __shared__ __attribute__((aligned(16))) char smem_n3[];
+  char* wl = smem_n3;
+  const int xbytes = a.xl_floats * 4;
+  char* xb0 = smem_n3 + WBYTES;
+  float* red = reinterpret_cast<float*>(xb0 + 2 * xbytes);
+  const int npix = a.IH * a.IW;
+  const bool producer = threadIdx.x >= 256;
+  const int tid = producer ? (int)threadIdx.x - 256 : (int)threadIdx.x;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);           // contiguous tile ranges per XCD at every iteration: halo neighbours share an L2
+
+  // filter: global [plane][k-step][cov][32] -> LDS, verbatim
+  for (int e = threadIdx.x; e < WBYTES / 16; e += 512)
+    reinterpret_cast<float4*>(wl)[e] = reinterpret_cast<const float4*>(a.w)[e];
+
+  if (producer) {
+    auto stage = [&](int tile, char* buf) {
+      const TileInfo ti = decode_tile<KIND>(a, tile, COT);
+      N3Regs<TWO> r;
+      n3_load<CIN, TWO>(r, a, ti, tid, npix);
+      if (TWO) {
+        if (a.in_mode == RCV_LOAD_GRAD_ENC) n3_store<RCV_LOAD_GRAD_ENC, CIN, TWO>(r, a, buf, tid, npix);
+        else n3_store<RCV_LOAD_GRAD_DEC, CIN, TWO>(r, a, buf, tid, npix);
+      } else {
+        switch (a.in_mode) {
+          case RCV_LOAD_PLAIN: n3_store<RCV_LOAD_PLAIN, CIN, TWO>(r, a, buf, tid, npix); break;
+          case RCV_LOAD_AFFINE: n3_store<RCV_LOAD_AFFINE, CIN, TWO>(r, a, buf, tid, npix); break;
+          default: n3_store<RCV_LOAD_AFFINE_RELU, CIN, TWO>(r, a, buf, tid, npix); break;
+        }
+      }
+    };
+    // barrier for barrier the consumer path: 1 + one per tile (+ the statistics reduction's)
+    if (wg < a.total_tiles) stage(wg, xb0);
+    __syncthreads();
+    int it = 0;
+    for (int tile = wg; tile < a.total_tiles; tile += gridDim.x, ++it) {
+      const int next = tile + gridDim.x;
+      if (next < a.total_tiles) stage(next, xb0 + ((it + 1) & 1) * xbytes);
+      __syncthreads();
+    }
+    if (a.stats != RCV_STATS_NONE) __syncthreads();
+    return;
+  }
+
+  // ---------------- consumer waves (4, side by side along the pixels) ----------------
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int s = KIND == KIND_GATHER ? a.stride : 1;
+  f32x4 acc[WM][WN];
+  float s1[WM][4], s2[WM][4];
+#pragma unroll
+  for (int m = 0; m < WM; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[m][r] = 0.f; s2[m][r] = 0.f; }
+  int pixoff[WN];
+#pragma unroll
+  for (int n = 0; n < WN; ++n) {
+    const int p = (wave * WN + n) * 16 + l15;
+    int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
+    if (ty >= a.R) { ty = 0; tx = 0; }
+    pixoff[n] = ((ty * s) * a.IW + tx * s) * PITCH;
+  }
+  // per k-step: tap shift and channel offset of this lane's eight k (k = 32 ks + 8 g: one tap, eight consecutive channels)
+  int koff[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const int k0 = 32 * ks + 8 * l4;
+    int tap = k0 / CIN, ci0 = k0 % CIN;
+    if (tap >= TAPS) { tap = 0; ci0 = 0; }                  // beyond the last tap the filter is zero: read any finite data
+    const int shift = KIND == KIND_GATHER ? (tap / 3) * a.IW + (tap % 3) : (tap >> 1) * a.IW + (tap & 1);
+    koff[ks] = shift * PITCH + 2 * ci0;
+  }
+  const char* abase = wl + l15 * 64 + l4 * 16;
+
+  __syncthreads();
+  int it = 0;
+  for (int tile = wg; tile < a.total_tiles; tile += gridDim.x, ++it) {
+    const char* xb = xb0 + (it & 1) * xbytes;
+#pragma unroll
+    for (int m = 0; m < WM; ++m)
+#pragma unroll
+      for (int n = 0; n < WN; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    n3_bf16x8 A[2][WM][3], B[2][3];
+    auto load_a = [&](int ks, n3_bf16x8 (&dst)[WM][3]) {
+#pragma unroll
+      for (int m = 0; m < WM; ++m)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[m][pl] = *reinterpret_cast<const n3_bf16x8*>(abase + pl * WPLANE + (ks * COT + m * 16) * 64);
+    };
+    auto load_b = [&](int ks, int n, n3_bf16x8 (&dst)[3]) {
+      const char* pb = xb + pixoff[n] + koff[ks];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const n3_bf16x8*>(pb + pl * 2 * CIN);
+    };
+    load_a(0, A[0]);
+    load_b(0, 0, B[0]);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      if (ks + 1 < NKS) load_a(ks + 1, A[(ks + 1) & 1]);
+#pragma unroll
+      for (int n = 0; n < WN; ++n) {
+        const int i = ks * WN + n;                           // step counter: B double buffer
+        if (n + 1 < WN) load_b(ks, n + 1, B[(i + 1) & 1]);
+        else if (ks + 1 < NKS) load_b(ks + 1, 0, B[(i + 1) & 1]);
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};     // smallest products first
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+#pragma unroll
+          for (int m = 0; m < WM; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ks & 1][m][TA[e]], B[i & 1][TB[e]], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const TileInfo ti = decode_tile<KIND>(a, tile, COT);
+    // (EB = WN: the residual / BatchNorm-backward operands of all pixel blocks of a channel block are requested in ONE batch; loaded where
+    // they are used they are 2 * WN serialized HBM round trips per tile, and nothing hides them here)
+    conv_epilogue_tile<WM, WN, 1, 4, KIND, WN>(a, ti, acc, s1, s2, tid);
+    __syncthreads();
+  }
+  if (a.stats != RCV_STATS_NONE) conv_epilogue_stats<WM, 1, 4, KIND>(a, (size_t)blockIdx.x, 0, s1, s2, red, tid);
+}
+
+// --------------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------------
+struct N3Geom { int WN, R, Wt, IH, IW, tiles_x, tiles_y, total, grid, xl_bytes; size_t lds; };
+
+static inline int n3_nks(int kind, int Cin) { return ((kind == KIND_GATHER ? 9 : 4) * Cin + 31) / 32; }
+
+static bool n3_shape_ok(const rcv_op* op, int kind) {
+  const int Cin = op->i[RCV_I_CIN], Cout = op->i[RCV_I_COUT];
+  if (!(Cin == 8 || Cin == 16 || Cin == 32) || Cout % 4) return false;
+  if (op->i[RCV_I_INMODE] == RCV_LOAD_NCHW || op->i[RCV_I_DIL] != 1) return false;
+  const int CoutP = round_up(kind == KIND_TMERGED ? 4 * Cout : Cout, 16);
+  if (kind == KIND_GATHER) return (CoutP == 16 || CoutP == 32) && (op->i[RCV_I_STRIDE] == 1 || op->i[RCV_I_STRIDE] == 2);
+  if (kind == KIND_TMERGED) return (Cin == 16 && CoutP == 32) || (Cin == 32 && CoutP == 64);
+  return false;
+}
+
+static bool n3_geometry(const rcv_handle* h, const rcv_op* op, int kind, N3Geom* g) {
+  const int N = op->i[RCV_I_N], Cin = op->i[RCV_I_CIN], Cout = op->i[RCV_I_COUT], s = op->i[RCV_I_STRIDE];
+  const int TH = kind == KIND_GATHER ? op->i[RCV_I_HO] : op->i[RCV_I_H], TW = kind == KIND_GATHER ? op->i[RCV_I_WO] : op->i[RCV_I_W];
+  const int CoutP = round_up(kind == KIND_TMERGED ? 4 * Cout : Cout, 16);
+  const size_t wbytes = 3 * (size_t)n3_nks(kind, Cin) * CoutP * 64;
+  const int per_pass = 256 / (Cin / 4);
+  double best = 1e30;
+  bool found = false;
+  for (int WN : {5, 3}) {
+    const int slots = 64 * WN;
+    for (int nx = 1; nx <= TW; ++nx) {
+      const int wt = ceil_div(TW, nx);
+      if (wt > slots) continue;
+      if (nx > 1 && wt < 8) break;
+      int r = slots / wt < TH ? slots / wt : TH;
+      for (; r >= 1; --r) {
+        const int rb = ceil_div(TH, ceil_div(TH, r));
+        int ih, iw;
+        tile_halo(kind, rb, wt, s, 1, &ih, &iw);
+        if (ih * iw > N3_NU * per_pass) continue;
+        const int xl = round_up(ih * iw * 6 * Cin, 16);
+        const size_t lds = wbytes + 2 * (size_t)xl + (size_t)4 * 2 * CoutP * sizeof(float);
+        if (lds > (size_t)h->max_lds) continue;
+        const long tiles = (long)N * ceil_div(TW, wt) * ceil_div(TH, rb);
+        // per tile: the HBM stream of its pixels (with halo) + the MFMA slots + a fixed part
+        const double halo = (double)ih * iw / ((double)rb * wt * (kind == KIND_GATHER ? s * s : 1));
+        const double cost = (double)tiles * ((double)rb * wt * (1.0 + 0.5 * halo) + 0.35 * slots + 40.0);
+        if (cost < best) {
+          best = cost; found = true;
+          g->WN = WN; g->R = rb; g->Wt = wt; g->IH = ih; g->IW = iw; g->tiles_x = ceil_div(TW, wt); g->tiles_y = ceil_div(TH, rb);
+          g->total = (int)tiles; g->xl_bytes = xl; g->lds = lds;
+        }
+        break;
+      }
+    }
+  }
+  if (found) g->grid = g->total < h->num_cus ? g->total : h->num_cus;
+  return found;
+}
+
+// Would this record run here if its filter were packed in the split layout?  (rcv_op_filter_layout: 3 for a conv, 4 for a merged transposed conv)
+bool convn_bf3_wanted(const rcv_handle* h, const rcv_op* op) {
+  if (RCV_ENV("RCV_NO_BF3") || RCV_ENV("RCV_NO_BF3N") || (op->flags & RCV_F_MFMA_FP32)) return false;
+  const int kind = op->kind == RCV_OP_CONV ? KIND_GATHER : (op->kind == RCV_OP_TCONV ? KIND_TMERGED : -1);
+  if (kind < 0 || !n3_shape_ok(op, kind)) return false;
+  if ((long long)op->i[RCV_I_N] * op->i[RCV_I_H] * op->i[RCV_I_W] * op->i[RCV_I_CIN] >= (1ll << 31)) return false;
+  N3Geom g;
+  if (!n3_geometry(h, op, kind, &g)) return false;
+  if ((long)g.total * 2 < (long)h->num_cus) return false;   // small planes stay on the other kernels
+  if (RCV_ENV("RCV_BF3N_ALL")) return true;
+  // Where this kernel is the faster one (op by op at the shapes of the 640 x 480 step, scripts/experiments/exp_r3_n3ops.sh): the layers
+  // whose fp32 form is matrix-pipe bound -- 32 -> 32 (133 -> 86 us forward, 157 -> 107 data gradient), 16 -> 16 (136 -> 125, 186 -> 170),
+  // the 32 -> 16 transposed conv with a two-tensor input (202 -> 178).  The HBM-bound forms (8 -> 16 stride 2, the forward transposed
+  // convs: 102 -> 127, 115 -> 164 us) stream better through convs_mfma.hip, whose two workgroups per CU keep more loads in flight.
+  const int Cin = op->i[RCV_I_CIN], m = op->i[RCV_I_INMODE];
+  const bool two = m == RCV_LOAD_GRAD_ENC || m == RCV_LOAD_GRAD_DEC;
+  if (kind == KIND_GATHER) return Cin == 32 || (Cin == 16 && op->i[RCV_I_STRIDE] == 1);
+  return Cin == 32 && two;
+}
+
+bool convn_bf3_supported(const rcv_handle* h, const rcv_op* op, int kind) {
+  const int aux = op->i[RCV_I_AUX0];
+  return ((kind == KIND_GATHER && aux == 3) || (kind == KIND_TMERGED && aux == 4)) && op->i[RCV_I_CIN] <= 32;
+}
+
+int convn_bf3_plan(const rcv_handle* h, const rcv_op* op, int kind, ConvPlan* pl) {
+  RCV_CHECK_ARG(n3_shape_ok(op, kind) && !(op->flags & RCV_F_MFMA_FP32), "split-bf16 narrow conv: shape %d -> %d (stride %d, dilation %d) not built",
+                op->i[RCV_I_CIN], op->i[RCV_I_COUT], op->i[RCV_I_STRIDE], op->i[RCV_I_DIL]);
+  N3Geom g;
+  RCV_CHECK_ARG(n3_geometry(h, op, kind, &g), "split-bf16 narrow conv: no tile fits");
+  const int Cout = op->i[RCV_I_COUT];
+  pl->kind = kind; pl->narrow = 0; pl->dma = 0; pl->first = 0; pl->wino = 0; pl->small = 0; pl->bf3 = 2;
+  pl->CK = op->i[RCV_I_CIN];
+  pl->CoutV = kind == KIND_TMERGED ? 4 * Cout : Cout; pl->CoutP = round_up(pl->CoutV, 16);
+  pl->WM = pl->CoutP / 16; pl->WN = g.WN;
+  pl->R = g.R; pl->Wt = g.Wt; pl->IH = g.IH; pl->IW = g.IW; pl->tiles_x = g.tiles_x; pl->tiles_y = g.tiles_y;
+  pl->n_co_tiles = 1; pl->n_phases = 1; pl->total_tiles = g.total; pl->grid = g.grid;
+  pl->xl_floats = g.xl_bytes / 4; pl->wl_floats = 0; pl->lds = g.lds;
+  return RCV_OK;
+}
+
+template <int CIN, int WM, int WN, int KIND, bool TWO>
+static int n3_launch_inst(const ConvPlan& pl, const ConvArgs& a, hipStream_t s) {
+  auto kern = convn_bf3_kernel<CIN, WM, WN, KIND, TWO>;
+  static size_t configured[RCV_MAX_DEVICES];
+  RCV_ENSURE_LDS(kern, pl.lds, pl.dev, configured);
+  hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(512), pl.lds, s, a);
+  RCV_HIP(hipGetLastError());
+  return RCV_OK;
+}
+template <int CIN, int WM, int KIND>
+static int n3_launch_wn(const ConvPlan& pl, const ConvArgs& a, bool two, hipStream_t s) {
+  if (pl.WN == 5) return two ? n3_launch_inst<CIN, WM, 5, KIND, true>(pl, a, s) : n3_launch_inst<CIN, WM, 5, KIND, false>(pl, a, s);
+  return two ? n3_launch_inst<CIN, WM, 3, KIND, true>(pl, a, s) : n3_launch_inst<CIN, WM, 3, KIND, false>(pl, a, s);
+}
+
+int convn_bf3_launch(const ConvPlan& pl, const ConvArgs& a, hipStream_t s) {
+  const bool two = a.in_mode == RCV_LOAD_GRAD_ENC || a.in_mode == RCV_LOAD_GRAD_DEC;
+  if (pl.kind == KIND_TMERGED) {
+    if (a.Cin == 16) return n3_launch_wn<16, 2, KIND_TMERGED>(pl, a, two, s);
+    return n3_launch_wn<32, 4, KIND_TMERGED>(pl, a, two, s);
+  }
+  switch (a.Cin * 10 + pl.WM) {
+    case 81: return n3_launch_wn<8, 1, KIND_GATHER>(pl, a, two, s);
+    case 82: return n3_launch_wn<8, 2, KIND_GATHER>(pl, a, two, s);
+    case 161: return n3_launch_wn<16, 1, KIND_GATHER>(pl, a, two, s);
+    case 162: return n3_launch_wn<16, 2, KIND_GATHER>(pl, a, two, s);
+    case 321: return n3_launch_wn<32, 1, KIND_GATHER>(pl, a, two, s);
+    default: return n3_launch_wn<32, 2, KIND_GATHER>(pl, a, two, s);
+  }
+}

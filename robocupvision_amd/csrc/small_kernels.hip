@@ -62,7 +62,8 @@ __global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
     }
     return;
   }
-  const int total = (jb.merged == 1 ? 4 : 9) * per_tap;
+  const bool par = jb.merged == 1 || jb.merged == 4;        // merged-parity layout of a transposed conv (4: the same, split into bf16)
+  const int total = (par ? 4 : 9) * per_tap;
   const int rows = jb.rows_from_d1 ? jb.D1 : jb.D0;
   const int cols = jb.rows_from_d1 ? jb.D0 : jb.D1;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
@@ -70,10 +71,11 @@ __global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
     const int rc = e - t * per_tap;
     const int row = rc / jb.cols_pad;
     int col = rc - row * jb.cols_pad;
+    const int vcol = col;               // (virtual) column of the packed layout
     float v = 0.f;
     int ts = jb.flip ? 8 - t : t;
     bool ok = row < rows && col < cols;
-    if (jb.merged == 1) {
+    if (par) {
       // virtual column = parity*cols + col; tap t = (dy,dx) of the 2x2 input window.
       // output row 2y+py takes input row y+dy through filter row ky: py=0: (dy=0,ky=1); py=1: (dy=0,ky=2),(dy=1,ky=0)
       const int ph = col / cols;
@@ -90,13 +92,14 @@ __global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
       v = jb.src[((size_t)d0 * jb.D1 + d1) * 9 + ts];
       if (jb.scale) v *= jb.scale[col];
     }
-    if (jb.merged == 3) {
-      // split-bf16 layout of conv_bf3.hip: v = h + m + l exactly (three round-to-nearest bf16 steps, every remainder exact);
-      // dst = [plane][tap][row / 32][col][row % 32] bf16 -- the eight consecutive input channels a lane of v_mfma_f32_16x16x32_bf16
-      // holds are 16 contiguous bytes
+    if (jb.merged >= 3) {
+      // split-bf16 layouts of conv_bf3.hip / convn_bf3.hip: v = h + m + l exactly (three round-to-nearest bf16 steps, every remainder
+      // exact); with k = tap * rows_pad + row, dst = [plane][k / 32][col][k % 32] bf16 (k-steps padded to 32, zero beyond the last tap)
+      // -- the eight consecutive k a lane of v_mfma_f32_16x16x32_bf16 holds are 16 contiguous bytes
       __bf16* d16 = reinterpret_cast<__bf16*>(jb.dst);
-      const size_t plane = (size_t)9 * per_tap;
-      const size_t o = (((size_t)t * (jb.rows_pad >> 5) + (row >> 5)) * jb.cols_pad + col) * 32 + (row & 31);
+      const int kk = t * jb.rows_pad + row;
+      const size_t plane = (size_t)(((par ? 4 : 9) * jb.rows_pad + 31) >> 5) * jb.cols_pad * 32;
+      const size_t o = ((size_t)(kk >> 5) * jb.cols_pad + vcol) * 32 + (kk & 31);
       const __bf16 hh = (__bf16)v;
       const float r1 = v - (float)hh;
       const __bf16 mm = (__bf16)r1;

@@ -262,10 +262,13 @@ class _Lowering:
     def add_pack(self, param, D0, D1, rows_from_d1, flip, merged=False, wino=0, scale: Optional[torch.Tensor] = None):
         """wino: the layout rcv_op_filter_layout asked for (0 plain, 2 Winograd, 3 split-bf16: three bf16 per value, rows padded to 32)."""
         wino = int(wino)
+        merged = bool(merged) or wino == 4
         rows = D1 if rows_from_d1 else D0
         cols = D0 if rows_from_d1 else D1
-        rp, cp = _round_up(rows, 32 if wino == 3 else 4), _round_up(cols * (4 if merged else 1), 16)
-        n_floats = 16 * rp * cp if wino == 2 else ((9 * rp * cp * 3) // 2 if wino == 3 else (4 if merged else 9) * rp * cp)
+        split = wino in (3, 4)      # three bf16 per value, k = tap * rows + row in steps of 32 (zero beyond the last tap)
+        rp, cp = _round_up(rows, (32 if rows > 32 else 8) if split else 4), _round_up(cols * (4 if merged else 1), 16)
+        taps = 16 if wino == 2 else (4 if merged else 9)
+        n_floats = 3 * ((taps * rp + 31) // 32) * cp * 16 if split else taps * rp * cp
         dst = self.eng._zeros(self.plan, n_floats)
         j = L.RcvPackJob()
         j.src, j.dst, j.D0, j.D1 = param.data_ptr(), dst.data_ptr(), D0, D1
@@ -277,12 +280,20 @@ class _Lowering:
 
     def wants_winograd(self, op: L.RcvOp) -> int:
         """Ask the library which filter layout this conv record should get (0 plain, 2 Winograd, 3 split-bf16) and mark the record."""
-        if WINOGRAD == "off":
-            return 0
         layout = L.op_filter_layout(self.eng.handle, op, WINOGRAD == "force")
+        if layout == 2 and WINOGRAD == "off":
+            layout = 0
         if layout:
             op.i[L.RCV_I_AUX0] = layout
         return layout
+
+    def tconv_layout(self, op: L.RcvOp) -> int:
+        """The same question for a transposed-conv record whose filter would be packed in the merged layout (i[AUX0] = 1): 4 = the library
+        runs it on the split-bf16 narrow kernel and wants the merged layout split into bf16 (the record is marked)."""
+        if op.i[L.RCV_I_AUX0] == 1 and L.op_filter_layout(self.eng.handle, op, False) == 4:
+            op.i[L.RCV_I_AUX0] = 4
+            return 4
+        return 0
 
     def side(self, op: L.RcvOp, input_slot: Optional[tuple] = None):
         """A filter-gradient-side op of the node being lowered (filter gradient, its reduction, a bias memset).  ``input_slot`` =
@@ -402,23 +413,25 @@ class _Lowering:
             # consumer applies relu(bn(.)) as its load transform, and LabelProp's tail fuses exactly that form into the classifier.)
             self.bn_tensors(node, Cout)
             cst = node.t["consts"]
-            node.t["wp"] = self.add_pack(w, Cin, Cout, False, False, merged=self.use_merged(Cout), scale=cst)
             t = self.eng._alloc(self.plan, self.N, Ho, Wo, Cout)
             op = L.make_op(L.OP_TCONV, L.F_BIAS | L.F_RELU | L.F_RESID, n=self.N, h=src.H, w=src.W, cin=Cin,
                            cout=Cout, ho=Ho, wo=Wo, stride=2, dil=1, aux0=int(self.use_merged(Cout)), inmode=src.load_mode,
-                           p_in_c=_ptr(src.consts), p_w=node.t["wp"].data_ptr(), p_bias=cst.data_ptr() + 4 * 3 * Cout, p_out=t.data_ptr(),
+                           p_in_c=_ptr(src.consts), p_bias=cst.data_ptr() + 4 * 3 * Cout, p_out=t.data_ptr(),
                            p_resid=skip.buf.data_ptr())
+            node.t["wp"] = self.add_pack(w, Cin, Cout, False, False, merged=self.use_merged(Cout), wino=self.tconv_layout(op), scale=cst)
+            op.p[L.RCV_P_W] = node.t["wp"].data_ptr()
             op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
             self.emit_bn_forward(node, bn, op, Cout, Ho, Wo, conv_bias=b)
             node.t["t"] = t
             node.out = Value("plain", t, Cout, Ho, Wo, None, node)
             return
-        node.t["wp"] = self.add_pack(w, Cin, Cout, False, False, merged=self.use_merged(Cout))
         t = self.eng._alloc(self.plan, self.N, Ho, Wo, Cout)
         self.bn_tensors(node, Cout)
         op = L.make_op(L.OP_TCONV, (L.F_BIAS if b is not None else 0), n=self.N, h=src.H, w=src.W, cin=Cin, cout=Cout,
                        ho=Ho, wo=Wo, stride=2, dil=1, aux0=int(self.use_merged(Cout)), inmode=src.load_mode, p_in_c=_ptr(src.consts),
-                       p_w=node.t["wp"].data_ptr(), p_bias=_ptr(b), p_out=t.data_ptr())
+                       p_bias=_ptr(b), p_out=t.data_ptr())
+        node.t["wp"] = self.add_pack(w, Cin, Cout, False, False, merged=self.use_merged(Cout), wino=self.tconv_layout(op))
+        op.p[L.RCV_P_W] = node.t["wp"].data_ptr()
         op.p[L.RCV_P_IN] = self.bind_in(self.fwd, src, L.RCV_P_IN) or None
         self.emit_bn_forward(node, bn, op, Cout, Ho, Wo)
         node.t["t"] = t
@@ -649,10 +662,14 @@ class _Lowering:
         if b is not None:   # bias ahead of a BatchNorm: gradient is identically zero
             self.side(L.make_op(L.OP_MEMSET, 0, count=b.numel(), p_out=self.fl.grad_ptr(b)))
         if src.needs_grad:
-            node.t["wd"] = self.add_pack(w, Cin, Cout, True, False)
             dop = L.make_op(L.OP_CONV, 0, n=self.N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=2, dil=1,
                             inmode=L.LOAD_GRAD_DEC, p_in=gout.data_ptr(), p_in_aux=node.t["t"].data_ptr(),
-                            p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
+                            p_in_c=node.t["bconsts"].data_ptr())
+            lay = self.wants_winograd(dop)
+            node.t["wd"] = self.add_pack(w, Cin, Cout, True, False, wino=(lay if lay in (3, 4) else 0))
+            if lay == 2:
+                dop.i[L.RCV_I_AUX0] = 0
+            dop.p[L.RCV_P_W] = node.t["wd"].data_ptr()
             self.grad_target(src, dop, src.H, src.W)
             self.bwd.append(dop)
         self.flush_side()
@@ -716,11 +733,12 @@ class _Lowering:
             else:
                 if src.H != 2 * out.H or src.W != 2 * out.W:
                     raise L.RcvError("stride-2 conv backward needs even input dims (got %dx%d)" % (src.H, src.W))
-                node.t["wd"] = self.add_pack(w, Cout, Cin, False, False, merged=self.use_merged(Cin))
                 dop = L.make_op(L.OP_TCONV, 0, n=self.N, h=out.H, w=out.W, cin=Cout, cout=Cin, ho=src.H, wo=src.W, stride=2, dil=1,
                                 aux0=int(self.use_merged(Cin)),
                                 inmode=gmode, p_in=out.grad.data_ptr(), p_in_aux=out.buf.data_ptr(),
-                                p_in_c=node.t["bconsts"].data_ptr(), p_w=node.t["wd"].data_ptr())
+                                p_in_c=node.t["bconsts"].data_ptr())
+                node.t["wd"] = self.add_pack(w, Cout, Cin, False, False, merged=self.use_merged(Cin), wino=self.tconv_layout(dop))
+                dop.p[L.RCV_P_W] = node.t["wd"].data_ptr()
             self.grad_target(src, dop, src.H, src.W)
             self.bwd.append(dop)
         self.flush_side()
@@ -814,7 +832,7 @@ class _Lowering:
             dev_table = host.to(self.eng.device)
             plan.keep.append(dev_table)
             assert C.sizeof(table) == dev_table.numel()
-            max_elems = max((4 if j.merged == 1 else 9) * j.rows_pad * j.cols_pad for j in self.jobs)
+            max_elems = max((4 if j.merged in (1, 4) else 9) * j.rows_pad * j.cols_pad for j in self.jobs)
             head += [L.make_op(L.OP_PACK, 0, count=len(self.jobs), aux0=max_elems, p_in=dev_table.data_ptr())]
         for slots in plan.input_slots:
             for i, (is_bwd, k, sl) in enumerate(slots):

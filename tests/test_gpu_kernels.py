@@ -33,6 +33,15 @@ def _load_fp64(mode, x, aux, c, L):
     return X
 
 
+def _pack_dims(rows, cols, layout, merged=False):
+    """rows_pad, cols_pad, floats of the packed filter for a layout of rcv_pack_job.merged (as engine._Lowering.add_pack sizes it)."""
+    split = layout in (3, 4)
+    rp = (rows + 31) // 32 * 32 if (split and rows > 32) else ((rows + 7) // 8 * 8 if split else (rows + 3) // 4 * 4)
+    cp = (cols * (4 if merged else 1) + 15) // 16 * 16
+    taps = 16 if layout == 2 else (4 if merged else 9)
+    return rp, cp, (3 * ((taps * rp + 31) // 32) * cp * 16 if split else taps * rp * cp)
+
+
 CONV_SHAPES = [(4, 15, 20, 64, 64, 1), (4, 15, 20, 128, 64, 1), (2, 30, 40, 128, 128, 1), (4, 30, 40, 64, 32, 1), (4, 15, 20, 64, 128, 1),
                (4, 30, 40, 32, 64, 2), (4, 30, 40, 32, 32, 1), (4, 60, 80, 16, 16, 1), (3, 5, 7, 64, 64, 1), (2, 37, 53, 32, 64, 1),
                (2, 120, 160, 8, 16, 2), (5, 9, 11, 128, 128, 1), (1, 60, 80, 64, 128, 2), (2, 48, 64, 16, 32, 2)]
@@ -51,11 +60,12 @@ def test_conv_kernels_vs_fp64(N, H, W, Cin, Cout, s, mode_name):
     ref = F.conv2d(_load_fp64(mode, x, xa, c, L).permute(0, 3, 1, 2), w.double(), stride=s, padding=1).permute(0, 2, 3, 1) + resid.double()
     xd, xad, cd, wd, rd = (v.to(DEV) for v in (x, xa, c, w, resid))
     # filter layouts (rcv_op_filter_layout): 0 plain, 2 Winograd, 3 split-bf16 (conv_bf3.hip: fp32 products as six bf16 MFMA products)
+    # 3 on the wide stride-1 layers: conv_bf3.hip; on the 8 / 16 / 32 -> <= 32 channel layers (stride 1 | 2): convn_bf3.hip
     winos = [0] + ([2] if (s == 1 and Cin % 16 == 0 and Cin >= 32 and Cout >= 64) else []) + \
-            ([3] if (s == 1 and Cin % 32 == 0 and Cin >= 64 and Cout >= 64) else [])
+            ([3] if (s == 1 and Cin % 32 == 0 and Cin >= 64 and Cout >= 64) or (Cin in (8, 16, 32) and Cout <= 32) else [])
     for wino in winos:
-        rp, cp = (Cin + (31 if wino == 3 else 3)) // (32 if wino == 3 else 4) * (32 if wino == 3 else 4), (Cout + 15) // 16 * 16
-        wp = torch.zeros((16 if wino else 9) * rp * cp, device=DEV)
+        rp, cp, nfl = _pack_dims(Cin, Cout, wino)
+        wp = torch.zeros(nfl, device=DEV)
         job = L.RcvPackJob()
         job.src, job.dst, job.D0, job.D1 = wd.data_ptr(), wp.data_ptr(), Cout, Cin
         job.rows_from_d1, job.flip, job.rows_pad, job.cols_pad, job.merged = 1, 0, rp, cp, wino
@@ -67,7 +77,7 @@ def test_conv_kernels_vs_fp64(N, H, W, Cin, Cout, s, mode_name):
                          p_out=out.data_ptr(), p_resid=rd.data_ptr())
         lst = L.OpList([pack, conv])
         label = lst.labels(h)[1]
-        assert label.startswith("conv_wino") == (wino == 2) and label.startswith("conv_bf3") == (wino == 3), label
+        assert label.startswith("conv_wino") == (wino == 2) and ("_bf3" in label) == (wino == 3), label
         lst.run(h, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
@@ -215,22 +225,28 @@ def test_transposed_conv_kernels_vs_fp64(N, H, W, Cin, Cout, mode_name):
                              output_padding=1).permute(0, 2, 3, 1)
     xd, xad, cd, wd, bd = (v.to(DEV) for v in (x, xa, c, w, bias))
     merged = 1 if Cout <= MERGED_TCONV_MAX_COUT else 0
-    rp, cp = (Cin + 3) // 4 * 4, (Cout * (4 if merged else 1) + 15) // 16 * 16
-    wp = torch.zeros((4 if merged else 9) * rp * cp, device=DEV)
-    job = L.RcvPackJob()
-    job.src, job.dst, job.D0, job.D1 = wd.data_ptr(), wp.data_ptr(), Cin, Cout
-    job.rows_from_d1, job.flip, job.rows_pad, job.cols_pad, job.merged = 0, 0, rp, cp, merged
-    table = torch.frombuffer(bytearray(bytes((L.RcvPackJob * 1)(job))), dtype=torch.uint8).to(DEV)
-    out = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device=DEV)
-    pack = L.make_op(L.OP_PACK, 0, count=1, aux0=9 * rp * cp, p_in=table.data_ptr())
-    tconv = L.make_op(L.OP_TCONV, L.F_BIAS, n=N, h=H, w=W, cin=Cin, cout=Cout, ho=2 * H, wo=2 * W, stride=2, dil=1, inmode=mode, aux0=merged,
-                      p_in=xd.data_ptr(), p_in_aux=xad.data_ptr(), p_in_c=cd.data_ptr(), p_w=wp.data_ptr(), p_bias=bd.data_ptr(),
-                      p_out=out.data_ptr())
-    lst = L.OpList([pack, tconv])
-    lst.run(h, torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
-    assert err <= 3e-6, (lst.labels(h)[1], err)
+    # merged layout as it is (fp32 kernels) and, where the split-bf16 narrow kernel is built, split into bf16 (layout 4: tconvn_bf3)
+    layouts = [merged] + ([4] if merged and (Cin, (4 * Cout + 15) // 16 * 16) in ((16, 32), (32, 64)) else [])
+    for layout in layouts:
+        rp, cp, nfl = _pack_dims(Cin, Cout, layout, merged=bool(merged))
+        wp = torch.zeros(nfl, device=DEV)
+        job = L.RcvPackJob()
+        job.src, job.dst, job.D0, job.D1 = wd.data_ptr(), wp.data_ptr(), Cin, Cout
+        job.rows_from_d1, job.flip, job.rows_pad, job.cols_pad, job.merged = 0, 0, rp, cp, layout
+        table = torch.frombuffer(bytearray(bytes((L.RcvPackJob * 1)(job))), dtype=torch.uint8).to(DEV)
+        out = torch.full((N, 2 * H, 2 * W, Cout), float("nan"), device=DEV)
+        pack = L.make_op(L.OP_PACK, 0, count=1, aux0=9 * rp * cp, p_in=table.data_ptr())
+        tconv = L.make_op(L.OP_TCONV, L.F_BIAS, n=N, h=H, w=W, cin=Cin, cout=Cout, ho=2 * H, wo=2 * W, stride=2, dil=1, inmode=mode, aux0=layout,
+                          p_in=xd.data_ptr(), p_in_aux=xad.data_ptr(), p_in_c=cd.data_ptr(), p_w=wp.data_ptr(), p_bias=bd.data_ptr(),
+                          p_out=out.data_ptr())
+        lst = L.OpList([pack, tconv])
+        label = lst.labels(h)[1]
+        assert ("_bf3" in label) == (layout == 4), label
+        lst.run(h, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+        print(".%s %s: max error %.3e" % (label, (N, H, W, Cin, Cout), err))
+        assert err <= 3e-6, (label, err)
 
 
 @pytest.mark.parametrize("N,H,W,C", [(2, 8, 64, 8), (2, 6, 32, 16), (1, 4, 16, 32), (3, 10, 128, 8), (2, 6, 24, 8), (1, 4, 8, 64), (2, 4, 6, 16)])
