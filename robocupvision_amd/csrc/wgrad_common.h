@@ -68,3 +68,8 @@ int wgrad_first_launch(const rcv_handle* h, const WgradArgs& a, hipStream_t s);
 bool wgrad_bf3_supported(const rcv_handle* h, const rcv_op* op);
 void wgrad_bf3_geometry(const rcv_handle* h, const rcv_op* op, int* tw, int* tiles_x, int* tiles_y, int* nsplit, int* nctiles);
 int wgrad_bf3_launch(const rcv_handle* h, const WgradArgs& a, int tw, hipStream_t s);
+
+// narrow layers on the bf16 matrix pipe (wgradn_bf3.hip)
+bool wgradn_bf3_supported(const rcv_handle* h, const rcv_op* op);
+void wgradn_bf3_geometry(const rcv_handle* h, const rcv_op* op, int* th, int* tiles_x, int* tiles_y, int* ngroups);
+int wgradn_bf3_launch(const rcv_handle* h, const WgradArgs& a, int th, int ngroups, hipStream_t s);

@@ -570,6 +570,13 @@ static int wmake_plan(const rcv_handle* h, const rcv_op* op, WPlan* pl) {
     pl->R = 64 / pl->bf3; pl->Wt = pl->bf3; pl->Wt4 = pl->bf3; pl->IH = pl->R + 2; pl->IW = pl->bf3 + 2; pl->SP = 0; pl->SG = 0; pl->pl_floats = 0; pl->gl_floats = 0;
     return RCV_OK;
   }
+  if (wgradn_bf3_supported(h, op)) {    // narrow layers, the same arithmetic (wgradn_bf3.hip): bf3 = -(tile rows), four splits per workgroup
+    int th, ng;
+    wgradn_bf3_geometry(h, op, &th, &pl->tiles_x, &pl->tiles_y, &ng);
+    pl->bf3 = -th; pl->nsplit = 4 * ng; pl->nctiles = 1; pl->lds = 0; pl->grid = dim3(ng, 1, 1);
+    pl->R = th; pl->Wt = 16; pl->Wt4 = 16; pl->IH = (th - 1) * s + 3; pl->IW = 15 * s + 3; pl->SP = 0; pl->SG = 0; pl->pl_floats = 0; pl->gl_floats = 0;
+    return RCV_OK;
+  }
   // (an NCHW image with 4 channels does not fit the 2-block folded tile and the 5-block one carries no NCHW path: 16 x 16 tile)
   const bool fold = CA <= 8 && cbt_want == 16 && !(nchw && 9 * CA > 32) && !RCV_ENV("RCV_NO_FOLD");
   if (fold) pl->tile = 9 * CA <= 32 ? 7 : 8;
@@ -730,7 +737,8 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
     return RCV_OK;
   }
   if (query && pl.bf3) {
-    snprintf(query->label, sizeof(query->label), "wgrad_bf3<%d>", pl.bf3);
+    if (pl.bf3 > 0) snprintf(query->label, sizeof(query->label), "wgrad_bf3<%d>", pl.bf3);
+    else snprintf(query->label, sizeof(query->label), "wgradn_bf3<%d,%d>", -pl.bf3, op->i[RCV_I_STRIDE]);
     query->n_part = 0;
     query->n_split = pl.nsplit;
     query->part_bytes = (size_t)pl.nsplit * (9 * (size_t)pl.CBP * pl.CAP + pl.CBP) * sizeof(float);
@@ -766,6 +774,7 @@ int rcv_launch_wgrad(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQue
   RCV_CHECK_ARG(!p_two || a.p_aux, "wgrad: pointwise gradient load needs aux");
   a.part_bias = (op->flags & RCV_F_BIAS) ? a.part + (size_t)pl.nsplit * 9 * pl.CBP * pl.CAP : nullptr;
   if (pl.first) return wgrad_first_launch(h, a, s);
+  if (pl.bf3 < 0) return wgradn_bf3_launch(h, a, -pl.bf3, (int)pl.grid.x, s);
   if (pl.bf3) return wgrad_bf3_launch(h, a, pl.bf3, s);
   switch (pl.tile) {
     case 0: return wlaunch_inst<2, 2, 2, 2, 1, 0, true>(a, g_two, pl.grid, pl.lds, s, h->device);

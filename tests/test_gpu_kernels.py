@@ -119,7 +119,10 @@ WGRAD_SHAPES = [(4, 15, 20, 64, 64, 1), (4, 30, 40, 32, 64, 2), (4, 15, 20, 64, 
                 (4, 60, 80, 16, 16, 1), (4, 120, 160, 8, 16, 2), (2, 15, 20, 64, 64, 1), (4, 16, 20, 64, 64, 1), (4, 15, 24, 64, 64, 1),
                 (3, 5, 7, 64, 64, 1), (4, 10, 14, 128, 64, 1), (64, 15, 20, 64, 64, 1), (1, 30, 40, 64, 64, 1), (4, 7, 10, 128, 128, 1),
                 (2, 37, 53, 16, 32, 1), (2, 48, 64, 8, 8, 1), (3, 33, 47, 32, 16, 1), (2, 60, 80, 32, 64, 2), (2, 120, 160, 16, 32, 2),
-                (3, 14, 18, 64, 128, 2), (1, 96, 128, 8, 16, 2)]
+                (3, 14, 18, 64, 128, 2), (1, 96, 128, 8, 16, 2),
+                # planes with at least one 8 x 16 tile per CU: the narrow layers' split-bf16 kernel (wgradn_bf3.hip), every channel-tile shape
+                (8, 64, 128, 16, 16, 1), (8, 64, 128, 32, 32, 1), (8, 128, 128, 16, 16, 2), (8, 128, 128, 16, 32, 2), (6, 60, 100, 32, 16, 1),
+                (5, 72, 112, 16, 32, 1), (8, 128, 128, 32, 32, 2), (6, 62, 100, 16, 24, 1), (8, 128, 128, 32, 16, 2)]
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,s", WGRAD_SHAPES)
@@ -168,6 +171,7 @@ def test_filter_gradient_kernels_vs_fp64(N, H, W, Cin, Cout, s, modes):
     refb = gy64.sum((0, 1, 2))
     e = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
     eb = float((db.double().cpu() - refb).abs().max() / refb.abs().max()) if has_bias else 0.0
+    print(".%s %s %s: max error %.3e (bias %.3e)" % (lst.labels(h)[0], (N, H, W, Cin, Cout, s), modes, e, eb))
     assert e <= 5e-7 and eb <= 5e-7, (lst.labels(h)[0], e, eb)
 
 
@@ -202,6 +206,7 @@ def test_filter_gradient_nchw_image_vs_fp64(N, H, W, Cin, Cout, s, d, two):
     refb = gy64.sum((0, 1, 2))
     e = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
     eb = float((db.double().cpu() - refb).abs().max() / refb.abs().max())
+    print(".%s %s: max error %.3e (bias %.3e)" % (lst.labels(h)[0], (N, H, W, Cin, Cout, s, d, two), e, eb))
     assert e <= 5e-7 and eb <= 5e-7, (lst.labels(h)[0], e, eb)
 
 
