@@ -202,7 +202,7 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(const ConvArgs a) {
       {
         int t3 = tap + 3, c3 = c;
         if (t3 >= 9) { t3 -= 9; c3 += 1; }
-        load_a(t3, c3, A[tap % 3]);
+        if (!(a.flags & RCV_F_DBG_NOSKIP)) load_a(t3, c3, A[tap % 3]);      // (ablation: the fragments of the first three k-steps for all)
       }
     }
     __syncthreads();

@@ -31,3 +31,5 @@ cd $GRAFT_REPO_ROOT && bash scripts/pmc_op.sh ${TAG}_conv128 conv 32 30 40 128 1
 echo "pmc exit=$?"
 cd $GRAFT_REPO_ROOT && bash scripts/pmc_op.sh ${TAG}_wino128 conv 32 30 40 128 128 --mode affine --stats fwd --wino 1 > /dev/null 2>&1
 echo "pmc wino exit=$?"
+cd $GRAFT_REPO_ROOT && bash scripts/pmc_op.sh ${TAG}_bf3conv128 conv 32 30 40 128 128 --mode affine --stats fwd --wino 3 > /dev/null 2>&1
+echo "pmc bf3 exit=$?"

@@ -41,5 +41,8 @@ if os.path.exists(pmc):
 pmc = "gpurun_out/pmc_%s_wino128.txt" % tag
 if os.path.exists(pmc):
     shutil.copy(pmc, "profiles/%s_conv_wino_128_sq_counters.txt" % tag)
+pmc = "gpurun_out/pmc_%s_bf3conv128.txt" % tag
+if os.path.exists(pmc):
+    shutil.copy(pmc, "profiles/%s_conv_bf3_128_sq_counters.txt" % tag)
 for k, v in list(out.items())[:8]:
     print("%-58s n=%3d %9.1f MB/launch" % (k[:58], v["launches"], v["hbm_bytes_per_launch"] / 1e6))
