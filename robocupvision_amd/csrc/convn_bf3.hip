@@ -124,13 +124,19 @@ __global__ __launch_bounds__(512) void convn_bf3_kernel(const ConvArgs a) {
         }
       }
     };
-    // barrier for barrier the consumer path: 1 + one per tile (+ the statistics reduction's)
-    if (wg < a.total_tiles) stage(wg, xb0);
+    // barrier for barrier the consumer path: 1 + one per tile (+ the statistics reduction's).
+    // (Round 3, measured and not kept: a second register set, so that the loads of tile i + 2 are issued before the data of tile i + 1 is
+    // consumed -- 8 -> 16 stride 2 forward 0.127 -> 0.125 ms, 16 -> 8 transposed 0.164 -> 0.154: the compiler waits vmcnt(0) at the loop's
+    // join points whatever is in flight.  Ablations (scripts/experiments/exp_r3_n3abl.sh) put the HBM-bound forms' time elsewhere: the
+    // transposed form spends 90 of its 167 us in the epilogue (conv_epilogue.h stores 16-byte pieces 64 bytes apart, two lanes per
+    // output pixel; convs_mfma.hip writes whole output rows per wave), the 8-channel stride-2 form 97 of 128 us in staging.)
+    const bool do_stage = !(a.flags & RCV_F_DBG_NOSTAGE);           // (ablation timings: scripts/bench_op.py --flags)
+    if (wg < a.total_tiles && do_stage) stage(wg, xb0);
     __syncthreads();
     int it = 0;
     for (int tile = wg; tile < a.total_tiles; tile += gridDim.x, ++it) {
       const int next = tile + gridDim.x;
-      if (next < a.total_tiles) stage(next, xb0 + ((it + 1) & 1) * xbytes);
+      if (next < a.total_tiles && do_stage) stage(next, xb0 + ((it + 1) & 1) * xbytes);
       __syncthreads();
     }
     if (a.stats != RCV_STATS_NONE) __syncthreads();
@@ -189,6 +195,7 @@ __global__ __launch_bounds__(512) void convn_bf3_kernel(const ConvArgs a) {
     };
     load_a(0, A[0]);
     load_b(0, 0, B[0]);
+    if (!(a.flags & RCV_F_DBG_NOMFMA))
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       if (ks + 1 < NKS) load_a(ks + 1, A[(ks + 1) & 1]);
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(512) void convn_bf3_kernel(const ConvArgs a) {
     const TileInfo ti = decode_tile<KIND>(a, tile, COT);
     // (EB = WN: the residual / BatchNorm-backward operands of all pixel blocks of a channel block are requested in ONE batch; loaded where
     // they are used they are 2 * WN serialized HBM round trips per tile, and nothing hides them here)
-    conv_epilogue_tile<WM, WN, 1, 4, KIND, WN>(a, ti, acc, s1, s2, tid);
+    if (!(a.flags & RCV_F_DBG_NOEPI)) conv_epilogue_tile<WM, WN, 1, 4, KIND, WN>(a, ti, acc, s1, s2, tid);
     __syncthreads();
   }
   if (a.stats != RCV_STATS_NONE) conv_epilogue_stats<WM, 1, 4, KIND>(a, (size_t)blockIdx.x, 0, s1, s2, red, tid);
