@@ -86,6 +86,87 @@ __device__ __forceinline__ void n3_store(const N3Regs<TWO>& r, const ConvArgs& a
   }
 }
 
+// Epilogue of a tile that lies entirely inside the plane, with everything that does not depend on the tile computed ONCE per (persistent)
+// workgroup: the lane's output offsets relative to the tile's first output element, its bias and BatchNorm-backward constants.  The
+// shared epilogue (conv_epilogue.h) redoes a division, two multiplies and a 64-bit offset per pixel block per tile -- on the HBM-bound
+// layers the consumer waves' epilogue was the longest phase of a tile.  Ragged tiles at the plane's edges take the shared one.
+template <int WM, int WN>
+struct N3Epi {
+  int off[WM][WN];            // element offset from the tile's first output element; < 0: the lane has no output element there
+  int co[WM];                 // the lane's first real output channel of block m; < 0: beyond the layer's channels
+};
+template <int WM, int WN, int KIND>
+__device__ __forceinline__ void n3_epi_setup(N3Epi<WM, WN>& E, const ConvArgs& a, int wave, int l15, int l4) {
+#pragma unroll
+  for (int m = 0; m < WM; ++m) {
+    const int cov = m * 16 + 4 * l4;
+    int co = cov, chan = cov;
+    if (KIND == KIND_TMERGED) { const int ph = cov / a.Cout; co = cov - ph * a.Cout; chan = ((ph >> 1) * a.Wo + (ph & 1)) * a.Cout + co; }
+    const bool co_ok = cov < a.CoutV;
+    E.co[m] = co_ok ? co : -1;
+#pragma unroll
+    for (int b = 0; b < WN; ++b) {
+      const int p = (wave * WN + b) * 16 + l15;
+      const int ty = fd_div(p, a.fdWt), tx = p - ty * a.Wt;
+      const int pix = KIND == KIND_TMERGED ? (2 * ty * a.Wo + 2 * tx) * a.Cout : (ty * a.Wo + tx) * a.Cout;
+      E.off[m][b] = (ty < a.R && co_ok) ? pix + chan : -1;
+    }
+  }
+}
+template <int WM, int WN>
+__device__ __forceinline__ void n3_epi_tile(const N3Epi<WM, WN>& E, const ConvArgs& a, size_t base, f32x4 (&acc)[WM][WN], float (&s1)[WM][4], float (&s2)[WM][4]) {
+  float* __restrict__ out = a.out + base;
+  const float* __restrict__ resid = a.resid + base;
+  const float* __restrict__ eaux = a.epi_aux + base;
+  const bool bwd_stats = a.stats == RCV_STATS_BWD_ENC || a.stats == RCV_STATS_BWD_DEC;
+#pragma unroll
+  for (int m = 0; m < WM; ++m) {
+    float4 rr[WN], ee[WN];
+    if (a.flags & RCV_F_RESID) {
+#pragma unroll
+      for (int b = 0; b < WN; ++b) rr[b] = ld4(resid + (E.off[m][b] < 0 ? 0 : E.off[m][b]));
+    }
+    if (bwd_stats) {
+#pragma unroll
+      for (int b = 0; b < WN; ++b) ee[b] = ld4(eaux + (E.off[m][b] < 0 ? 0 : E.off[m][b]));
+    }
+    // (per tile from L1: kept in registers across tiles they cost 16 registers per channel block and the 64-virtual-channel variants spilled)
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), e0 = bias, e1 = bias, mu = bias;
+    if (E.co[m] >= 0) {
+      if (a.flags & RCV_F_BIAS) bias = ld4(a.bias + E.co[m]);
+      if (a.stats == RCV_STATS_BWD_DEC) { e0 = ld4(a.epi_c + E.co[m]); e1 = ld4(a.epi_c + a.Cout + E.co[m]); }
+      if (bwd_stats) mu = ld4(a.epi_c + 2 * a.Cout + E.co[m]);
+    }
+#pragma unroll
+    for (int b = 0; b < WN; ++b) {
+      if (E.off[m][b] < 0) continue;
+      float4 v = make_float4(acc[m][b][0] + bias.x, acc[m][b][1] + bias.y, acc[m][b][2] + bias.z, acc[m][b][3] + bias.w);
+      if (a.flags & RCV_F_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (a.flags & RCV_F_RESID) { v.x += rr[b].x; v.y += rr[b].y; v.z += rr[b].z; v.w += rr[b].w; }
+      *reinterpret_cast<float4*>(out + E.off[m][b]) = v;
+      if (a.stats == RCV_STATS_FWD) {
+        s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+        s2[m][0] = fmaf(v.x, v.x, s2[m][0]); s2[m][1] = fmaf(v.y, v.y, s2[m][1]);
+        s2[m][2] = fmaf(v.z, v.z, s2[m][2]); s2[m][3] = fmaf(v.w, v.w, s2[m][3]);
+      } else if (a.stats == RCV_STATS_BWD_ENC) {
+        const float4 e = ee[b];
+        s1[m][0] += v.x; s1[m][1] += v.y; s1[m][2] += v.z; s1[m][3] += v.w;
+        s2[m][0] = fmaf(v.x, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(v.y, e.y - mu.y, s2[m][1]);
+        s2[m][2] = fmaf(v.z, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(v.w, e.w - mu.w, s2[m][3]);
+      } else if (a.stats == RCV_STATS_BWD_DEC) {
+        const float4 e = ee[b];
+        const float gx = fmaf(e.x, e0.x, e1.x) > 0.f ? v.x : 0.f;
+        const float gy = fmaf(e.y, e0.y, e1.y) > 0.f ? v.y : 0.f;
+        const float gz = fmaf(e.z, e0.z, e1.z) > 0.f ? v.z : 0.f;
+        const float gw = fmaf(e.w, e0.w, e1.w) > 0.f ? v.w : 0.f;
+        s1[m][0] += gx; s1[m][1] += gy; s1[m][2] += gz; s1[m][3] += gw;
+        s2[m][0] = fmaf(gx, e.x - mu.x, s2[m][0]); s2[m][1] = fmaf(gy, e.y - mu.y, s2[m][1]);
+        s2[m][2] = fmaf(gz, e.z - mu.z, s2[m][2]); s2[m][3] = fmaf(gw, e.w - mu.w, s2[m][3]);
+      }
+    }
+  }
+}
+
 template <int CIN, int WM, int WN, int KIND, bool TWO>
 __global__ __launch_bounds__(512) void convn_bf3_kernel(const ConvArgs a) {
   constexpr int TAPS = KIND == KIND_GATHER ? 9 : 4;
@@ -172,6 +253,10 @@ __global__ __launch_bounds__(512) void convn_bf3_kernel(const ConvArgs a) {
     koff[ks] = shift * PITCH + 2 * ci0;
   }
   const char* abase = wl + l15 * 64 + l4 * 16;
+  constexpr bool FAST_EPI = WM <= 2;       // (the 64-virtual-channel variants have no registers left for the offset table: 45 spills)
+  N3Epi<FAST_EPI ? WM : 1, FAST_EPI ? WN : 1> E;
+  if constexpr (FAST_EPI) n3_epi_setup<WM, WN, KIND>(E, a, wave, l15, l4);
+  const int lim_h = KIND == KIND_GATHER ? a.Ho : a.H, lim_w = KIND == KIND_GATHER ? a.Wo : a.W;
 
   __syncthreads();
   int it = 0;
@@ -215,7 +300,17 @@ __global__ __launch_bounds__(512) void convn_bf3_kernel(const ConvArgs a) {
     const TileInfo ti = decode_tile<KIND>(a, tile, COT);
     // (EB = WN: the residual / BatchNorm-backward operands of all pixel blocks of a channel block are requested in ONE batch; loaded where
     // they are used they are 2 * WN serialized HBM round trips per tile, and nothing hides them here)
-    if (!(a.flags & RCV_F_DBG_NOEPI)) conv_epilogue_tile<WM, WN, 1, 4, KIND, WN>(a, ti, acc, s1, s2, tid);
+    if (!(a.flags & RCV_F_DBG_NOEPI)) {
+      bool fast = false;
+      if constexpr (FAST_EPI) {
+        if (ti.y0 + a.R <= lim_h && ti.x0 + a.Wt <= lim_w) {       // (uniform) the tile lies inside the plane: offsets precomputed
+          const int ym = KIND == KIND_TMERGED ? 2 : 1;
+          n3_epi_tile<WM, WN>(E, a, ((size_t)(ti.n * a.Ho + ym * ti.y0) * a.Wo + ym * ti.x0) * a.Cout, acc, s1, s2);
+          fast = true;
+        }
+      }
+      if (!fast) conv_epilogue_tile<WM, WN, 1, 4, KIND, WN>(a, ti, acc, s1, s2, tid);
+    }
     __syncthreads();
   }
   if (a.stats != RCV_STATS_NONE) conv_epilogue_stats<WM, 1, 4, KIND>(a, (size_t)blockIdx.x, 0, s1, s2, red, tid);
