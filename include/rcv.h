@@ -208,10 +208,12 @@ int rcv_join_side(rcv_handle* h, void* stream);
 int rcv_run_timed(rcv_handle* h, const rcv_op* ops, int n, void* stream, float* ms);
 
 /* Filter layout the library wants for an RCV_OP_CONV record before its filter is packed: 0 = [9 taps][Cin][Cout] (rcv_pack_job.merged
- * 0), 2 = Winograd F(2x2,3x3) transformed [16][Cin][Cout] (rcv_pack_job.merged 2), 3 = split-bf16 [3 planes][9][Cin / 32][Cout][32]
- * (rcv_pack_job.merged 3, rows padded to 32; 1.5 x the bytes of layout 0); the record then carries the answer in i[RCV_I_AUX0].  The
- * wide (Cin % 32 == 0, >= 64 channels) stride-1 layers whose grid covers the chip answer 3 -- or 2 when the record carries
- * RCV_F_MFMA_FP32; `force` != 0 answers 2 for every shape the Winograd kernel can run. */
+ * 0), 2 = Winograd F(2x2,3x3) transformed [16][Cin][Cout] (rcv_pack_job.merged 2), 3 / 4 / 5 = the split-bf16 layouts of
+ * rcv_pack_job.merged (1.5 x the bytes of the plain layout); the record then carries the answer in i[RCV_I_AUX0].  RCV_OP_CONV: the wide
+ * (Cin % 32 == 0, >= 64 channels) stride-1 layers whose grid covers the chip answer 3 (2 when the record carries RCV_F_MFMA_FP32), the
+ * wide stride-2 layers (Cin % 16 == 0, >= 32; Cout >= 64) answer 5, the 16 / 32-channel layers whose fp32 form is matrix-pipe bound 3;
+ * RCV_OP_TCONV records in the merged form (i[RCV_I_AUX0] = 1) answer 4 where the split-bf16 narrow kernel is the faster one;
+ * `force` != 0 answers 2 for every shape the Winograd kernel can run. */
 int rcv_op_filter_layout(const rcv_handle* h, const rcv_op* op, int force);
 
 /* Label of the kernel (template instantiation / tiling) the library launches for `op`, e.g.
@@ -228,8 +230,12 @@ typedef struct rcv_pack_job {
   int32_t rows_pad, cols_pad;
   int32_t merged;         /* 1: transposed-conv "merged parity" layout [4 taps (dy,dx)][rows][4*cols] (see conv_mfma.hip);
                            * 2: Winograd layout [16][rows][cols] = G g G^T (see conv_wino.hip);
-                           * 3: split-bf16 layout: every value as three bf16 (v = h + m + l exactly), dst = [plane][9][rows_pad / 32][cols_pad][32]
-                           *    bf16 (rows_pad % 32 == 0; 9 * rows_pad * cols_pad * 6 bytes; see conv_bf3.hip)                   */
+                           * 3: split-bf16 layout: every value as three bf16 (v = h + m + l exactly); with k = tap * rows_pad + row,
+                           *    dst = [plane][k / 32][cols_pad][k % 32] bf16 (k-steps of 32, zero beyond the last tap; rows_pad a multiple of 8,
+                           *    of 32 above 32; see conv_bf3.hip / convn_bf3.hip);
+                           * 4: layout 1 (merged parity, 4 taps, 4 * cols virtual columns) split the same way (convn_bf3.hip);
+                           * 5: split-bf16 in 16-row chunks for the stride-2 wide convs: k = tap * 16 + row % 16 inside chunk row / 16,
+                           *    dst = [plane][chunk][5 k-steps][cols_pad][32] bf16 (rows_pad a multiple of 16; conv2_bf3_kernel)      */
   int32_t reserved;
   const float* scale; /* NULL, or one factor per OUTPUT channel (column) applied while packing: inference folds an eval-mode BatchNorm
                        * that follows the conv directly (relu(bn(conv(x))), model.py:175,190-194) into the filter, w'[co] = w[co] * scale[co] */

@@ -190,7 +190,7 @@ int rcv_op_filter_layout(const rcv_handle* h, const rcv_op* op, int force) {
   if (!h || !op) return 0;
   if (force == 0 && convn_bf3_wanted(h, op)) return op->kind == RCV_OP_TCONV ? 4 : 3;     // split-bf16 layouts, narrow layers (convn_bf3.hip)
   if (op->kind != RCV_OP_CONV) return 0;
-  if (force == 0 && conv_bf3_wanted(h, op)) return 3;      // split-bf16 layout (conv_bf3.hip); force: the Winograd layout where it exists
+  if (force == 0 && conv_bf3_wanted(h, op)) return op->i[RCV_I_STRIDE] == 2 ? 5 : 3;      // split-bf16 layout (conv_bf3.hip); force: the Winograd layout where it exists
   return conv_wino_wanted(h, op, force != 0) ? 2 : 0;
 }
 

@@ -723,7 +723,7 @@ static int make_plan(const rcv_handle* h, const rcv_op* op, ConvPlan* pl) {
   pl->bf3 = 0;
   if (convn_bf3_supported(h, op, pl->kind)) return convn_bf3_plan(h, op, pl->kind, pl);
   if (conv_bf3_supported(h, op, pl->kind)) return conv_bf3_plan(h, op, pl);
-  RCV_CHECK_ARG(op->i[RCV_I_AUX0] != 3 && op->i[RCV_I_AUX0] != 4, "conv: a filter packed in a split-bf16 layout needs a record one of the split-bf16 kernels runs");
+  RCV_CHECK_ARG(op->i[RCV_I_AUX0] < 3 || op->i[RCV_I_AUX0] > 5, "conv: a filter packed in a split-bf16 layout needs a record one of the split-bf16 kernels runs");
   if (conv_wino_supported(h, op, pl->kind)) return conv_wino_plan(h, op, pl);
   RCV_CHECK_ARG(transposed || op->i[RCV_I_AUX0] != 2, "conv: a filter packed in the Winograd layout needs stride 1 / dilation 1");
   if (conv_first_supported(op, pl->kind)) return conv_first_plan(h, op, pl);
@@ -857,7 +857,7 @@ int rcv_launch_conv(const rcv_handle* h, const rcv_op* op, hipStream_t s, OpQuer
     if (pl.bf3 == 2) {
       snprintf(query->label, sizeof(query->label), "%sn_bf3<%d,%d,%d>", pl.kind == KIND_TMERGED ? "tconv" : "conv", pl.CK, pl.WM, pl.WN);
     } else if (pl.bf3) {
-      snprintf(query->label, sizeof(query->label), "conv_bf3<64,%d>", 32 * pl.WN);
+      snprintf(query->label, sizeof(query->label), "conv%s_bf3<64,%d>", op->i[RCV_I_STRIDE] == 2 ? "2" : "", 32 * pl.WN);
     } else if (pl.wino) {
       snprintf(query->label, sizeof(query->label), "conv_wino<64,%d>", 16 * pl.WN);
     } else if (pl.small) {

@@ -100,9 +100,12 @@ __global__ void pack_kernel(const rcv_pack_job* __restrict__ jobs) {
       // exact); with k = tap * rows_pad + row, dst = [plane][k / 32][col][k % 32] bf16 (k-steps padded to 32, zero beyond the last tap)
       // -- the eight consecutive k a lane of v_mfma_f32_16x16x32_bf16 holds are 16 contiguous bytes
       __bf16* d16 = reinterpret_cast<__bf16*>(jb.dst);
-      const int kk = t * jb.rows_pad + row;
-      const size_t plane = (size_t)(((par ? 4 : 9) * jb.rows_pad + 31) >> 5) * jb.cols_pad * 32;
-      const size_t o = ((size_t)(kk >> 5) * jb.cols_pad + vcol) * 32 + (kk & 31);
+      // (layout 5, the stride-2 wide convs: 16-channel chunks, k = tap * 16 + row % 16 inside chunk row / 16, five k-steps per chunk)
+      const bool ch16 = jb.merged == 5;
+      const int kk = ch16 ? t * 16 + (row & 15) : t * jb.rows_pad + row;
+      const int kstep = ch16 ? (row >> 4) * 5 + (kk >> 5) : (kk >> 5);
+      const size_t plane = (size_t)(ch16 ? (jb.rows_pad >> 4) * 5 : ((par ? 4 : 9) * jb.rows_pad + 31) >> 5) * jb.cols_pad * 32;
+      const size_t o = ((size_t)kstep * jb.cols_pad + vcol) * 32 + (kk & 31);
       const __bf16 hh = (__bf16)v;
       const float r1 = v - (float)hh;
       const __bf16 mm = (__bf16)r1;

@@ -265,10 +265,11 @@ class _Lowering:
         merged = bool(merged) or wino == 4
         rows = D1 if rows_from_d1 else D0
         cols = D0 if rows_from_d1 else D1
-        split = wino in (3, 4)      # three bf16 per value, k = tap * rows + row in steps of 32 (zero beyond the last tap)
-        rp, cp = _round_up(rows, (32 if rows > 32 else 8) if split else 4), _round_up(cols * (4 if merged else 1), 16)
+        split = wino in (3, 4, 5)   # three bf16 per value, k = tap * rows + row in steps of 32 (zero beyond the last tap); 5: 16-row chunks, 5 steps each
+        rp, cp = _round_up(rows, (16 if wino == 5 else (32 if rows > 32 else 8)) if split else 4), _round_up(cols * (4 if merged else 1), 16)
         taps = 16 if wino == 2 else (4 if merged else 9)
-        n_floats = 3 * ((taps * rp + 31) // 32) * cp * 16 if split else taps * rp * cp
+        ksteps = (rp // 16) * 5 if wino == 5 else (taps * rp + 31) // 32
+        n_floats = 3 * ksteps * cp * 16 if split else taps * rp * cp
         dst = self.eng._zeros(self.plan, n_floats)
         j = L.RcvPackJob()
         j.src, j.dst, j.D0, j.D1 = param.data_ptr(), dst.data_ptr(), D0, D1
@@ -666,7 +667,7 @@ class _Lowering:
                             inmode=L.LOAD_GRAD_DEC, p_in=gout.data_ptr(), p_in_aux=node.t["t"].data_ptr(),
                             p_in_c=node.t["bconsts"].data_ptr())
             lay = self.wants_winograd(dop)
-            node.t["wd"] = self.add_pack(w, Cin, Cout, True, False, wino=(lay if lay in (3, 4) else 0))
+            node.t["wd"] = self.add_pack(w, Cin, Cout, True, False, wino=(lay if lay in (3, 4, 5) else 0))
             if lay == 2:
                 dop.i[L.RCV_I_AUX0] = 0
             dop.p[L.RCV_P_W] = node.t["wd"].data_ptr()

@@ -42,8 +42,10 @@ if a.kind in ("conv", "tconv"):
     consts = torch.rand(5, Cin, generator=g).to(dev) + 0.5
     taps = 16 if a.wino else (4 if a.merged else 9)
     wp = rnd(taps * r4(Cin) * r16(Cout * (4 if a.merged else 1))) * 0.1
-    if a.wino == 3 or a.merged == 4:      # three bf16 planes [plane][k / 32][col][32]: any finite bf16 pattern will do for a timing
+    if a.wino in (3, 5) or a.merged == 4:      # three bf16 planes [plane][k / 32][col][32]: any finite bf16 pattern will do for a timing
         ksteps = ((4 if a.merged else 9) * ((Cin + 7) // 8 * 8) + 31) // 32
+        if a.wino == 5:
+            ksteps = (Cin + 15) // 16 * 5
         wp = (torch.randn(3 * ksteps * r16(Cout * (4 if a.merged else 1)) * 32, generator=g) * 0.1).to(torch.bfloat16).to(dev).view(torch.float32)
     out = torch.empty(N, Ho, Wo, Cout, device=dev)
     ea = rnd(N, Ho, Wo, Cout); resid = rnd(N, Ho, Wo, Cout); ec = torch.rand(5, Cout, generator=g).to(dev)

@@ -35,11 +35,14 @@ def _load_fp64(mode, x, aux, c, L):
 
 def _pack_dims(rows, cols, layout, merged=False):
     """rows_pad, cols_pad, floats of the packed filter for a layout of rcv_pack_job.merged (as engine._Lowering.add_pack sizes it)."""
-    split = layout in (3, 4)
+    split = layout in (3, 4, 5)
     rp = (rows + 31) // 32 * 32 if (split and rows > 32) else ((rows + 7) // 8 * 8 if split else (rows + 3) // 4 * 4)
+    if layout == 5:
+        rp = (rows + 15) // 16 * 16
     cp = (cols * (4 if merged else 1) + 15) // 16 * 16
     taps = 16 if layout == 2 else (4 if merged else 9)
-    return rp, cp, (3 * ((taps * rp + 31) // 32) * cp * 16 if split else taps * rp * cp)
+    ksteps = (rp // 16) * 5 if layout == 5 else (taps * rp + 31) // 32
+    return rp, cp, (3 * ksteps * cp * 16 if split else taps * rp * cp)
 
 
 CONV_SHAPES = [(4, 15, 20, 64, 64, 1), (4, 15, 20, 128, 64, 1), (2, 30, 40, 128, 128, 1), (4, 30, 40, 64, 32, 1), (4, 15, 20, 64, 128, 1),
@@ -62,7 +65,8 @@ def test_conv_kernels_vs_fp64(N, H, W, Cin, Cout, s, mode_name):
     # filter layouts (rcv_op_filter_layout): 0 plain, 2 Winograd, 3 split-bf16 (conv_bf3.hip: fp32 products as six bf16 MFMA products)
     # 3 on the wide stride-1 layers: conv_bf3.hip; on the 8 / 16 / 32 -> <= 32 channel layers (stride 1 | 2): convn_bf3.hip
     winos = [0] + ([2] if (s == 1 and Cin % 16 == 0 and Cin >= 32 and Cout >= 64) else []) + \
-            ([3] if (s == 1 and Cin % 32 == 0 and Cin >= 64 and Cout >= 64) or (Cin in (8, 16, 32) and Cout <= 32) else [])
+            ([3] if (s == 1 and Cin % 32 == 0 and Cin >= 64 and Cout >= 64) or (Cin in (8, 16, 32) and Cout <= 32) else []) + \
+            ([5] if (s == 2 and Cin % 16 == 0 and Cin >= 32 and Cout >= 64) else [])       # stride-2 wide: conv2_bf3_kernel
     for wino in winos:
         rp, cp, nfl = _pack_dims(Cin, Cout, wino)
         wp = torch.zeros(nfl, device=DEV)
@@ -77,7 +81,7 @@ def test_conv_kernels_vs_fp64(N, H, W, Cin, Cout, s, mode_name):
                          p_out=out.data_ptr(), p_resid=rd.data_ptr())
         lst = L.OpList([pack, conv])
         label = lst.labels(h)[1]
-        assert label.startswith("conv_wino") == (wino == 2) and ("_bf3" in label) == (wino == 3), label
+        assert label.startswith("conv_wino") == (wino == 2) and ("_bf3" in label) == (wino in (3, 5)), label
         lst.run(h, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
