@@ -16,6 +16,10 @@
 //      partial sums) is used as it is.
 // Workgroup tile: 64 output channels x (2 x WN) pixel blocks of 16 (WN = 10: 320 pixel slots, WN = 5: 160), pixels taken row-major
 // from a TH x TW rectangle (30 x 10 on the 30 x 40 planes of the 128-channel layers: 256 workgroups = one per CU).
+// (Measured and not kept, round 3: the same tile on v_mfma_f32_32x32x16_bf16 -- one 32-channel x five 32-pixel blocks per wave, pixel
+// pitch 208 B so that the 16-byte reads of a 32-pixel block are conflict free, the shared epilogue with a 32-lane pixel map.  The bare
+// MFMA loop of the micro-benchmark is 20 % faster in that form; the kernel was SLOWER: 128 -> 128 0.065 -> 0.069 ms forward,
+// 0.070 -> 0.080 data gradient, 64 -> 64 0.074 -> 0.083 / 0.085 -> 0.101, results identical to 1e-6.)
 #include <type_traits>
 #include "conv_common.h"
 #include "conv_epilogue.h"

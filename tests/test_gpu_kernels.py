@@ -47,7 +47,8 @@ def _pack_dims(rows, cols, layout, merged=False):
 
 CONV_SHAPES = [(4, 15, 20, 64, 64, 1), (4, 15, 20, 128, 64, 1), (2, 30, 40, 128, 128, 1), (4, 30, 40, 64, 32, 1), (4, 15, 20, 64, 128, 1),
                (4, 30, 40, 32, 64, 2), (4, 30, 40, 32, 32, 1), (4, 60, 80, 16, 16, 1), (3, 5, 7, 64, 64, 1), (2, 37, 53, 32, 64, 1),
-               (2, 120, 160, 8, 16, 2), (5, 9, 11, 128, 128, 1), (1, 60, 80, 64, 128, 2), (2, 48, 64, 16, 32, 2)]
+               (2, 120, 160, 8, 16, 2), (5, 9, 11, 128, 128, 1), (1, 60, 80, 64, 128, 2), (2, 48, 64, 16, 32, 2),
+               (32, 30, 40, 128, 128, 1), (16, 60, 80, 64, 64, 1)]      # (the planes of the 640 x 480 step: the 320-pixel tile of conv_bf3 = its 32x32x16 form)
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,s", CONV_SHAPES)
