@@ -160,3 +160,86 @@ def test_the_planner_routes_the_layers_of_the_headline_step_and_the_flag_switche
             L.op_workspace(h, op)
             label = L.OpList([op]).labels(h)[0]
             assert label.startswith(want if not flags else "wgrad_mfma"), (label, want, flags)
+
+
+@gpu
+def test_whole_step_both_matrix_paths_against_the_fp64_oracle(monkeypatch):
+    """The headline step (ROBO-UNet, 32 x 640 x 480: the only size at which every split-bf16 kernel is in the plan) lowered twice from
+    the same weights and inputs -- as bench.py runs it, and with every contraction on v_mfma_f32_16x16x4_f32 (what RCV_MFMA_FP32=1 sets
+    on every record) -- and the same step through the CPU oracle in float64.  Logits and loss of the two paths agree to 1e-5; their
+    gradients are judged against fp64, per parameter tensor, relative to its largest entry: the split path may not be further from
+    fp64 than the fp32-instruction path (the filter gradients of the BatchNorm'ed wide layers cancel to ~1e-2 of their terms, so BOTH
+    paths sit at 1e-2 .. 3e-2 relative there, 7e-7 absolute: measured worst tensor 2.73e-2 split, 2.70e-2 fp32 instruction)."""
+    import robocupvision_amd.model as M
+    from oracle import cpu_reference as O
+    from robocupvision_amd import _lib as L
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(32, 3, 480, 640, generator=g)
+    t = torch.randint(0, 5, (32, 480, 640), generator=g)
+    res = {}
+    sd0 = None
+    for name, flags in (("split", 0), ("fp32", L.F_MFMA_FP32)):
+        monkeypatch.setattr(L, "MATRIX_FLAGS", flags)
+        torch.manual_seed(12345678)
+        net = M.ROBO_UNet(noScale=True)
+        if sd0 is None:
+            sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        net = net.to(dev)
+        crit = M.CrossEntropyLoss2d(torch.tensor([1, 10, 30, 10, 2], dtype=torch.float32)).to(dev)
+        net.train()
+        pred = net(x.to(dev))
+        loss = crit(pred, t.to(dev))
+        loss.backward()
+        eng = net._get_engine()
+        plan = [pl for (shape, training), pl in eng.plans.items() if training][0]
+        labels = plan.fwd.labels(eng.handle) + plan.bwd.labels(eng.handle)
+        res[name] = (pred.detach().cpu(), float(loss.detach()), {k: p.grad.detach().cpu() for k, p in net.named_parameters()}, labels)
+        del net, pred, loss
+    kinds = {l.split("<")[0] for l in res["split"][3] if "_bf3" in l}
+    assert {"conv_bf3", "conv2_bf3", "convn_bf3", "tconvn_bf3", "wgrad_bf3", "wgradn_bf3"} <= kinds, kinds
+    assert not any("_bf3" in l for l in res["fp32"][3])
+    p3, p32 = res["split"][0], res["fp32"][0]
+    assert float((p3 - p32).abs().max() / p32.abs().max()) <= 1e-5
+    assert abs(res["split"][1] - res["fp32"][1]) <= 2e-6 * abs(res["fp32"][1])
+    # fp64: the oracle's forward on double tensors, autograd
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    try:
+        sd64 = {k: v.double().clone() for k, v in sd0.items()}
+        names = O.param_names(sd64)
+        for n in names:
+            sd64[n].requires_grad_(True)
+        cfg = O.NetConfig(noScale=True)
+        pred64 = O.robo_unet_forward(sd64, x.double(), cfg, training=True)
+        w = torch.tensor([1, 10, 30, 10, 2], dtype=torch.float64)
+        loss64 = torch.nn.functional.cross_entropy(pred64, t, weight=w)
+        loss64.backward()
+    finally:
+        torch.set_num_threads(old_threads)
+    assert abs(res["split"][1] - float(loss64)) <= 1e-5 * abs(float(loss64))
+    rows, worst3, worst32 = [], 0.0, 0.0
+    for n in names:
+        if n.startswith("upPart") and n.endswith("conv.bias"):
+            continue            # exactly zero (bias ahead of a BatchNorm)
+        g64 = sd64[n].grad
+        scale = float(g64.abs().max()) + 1e-30
+        e3 = float((res["split"][2][n].double() - g64).abs().max()) / scale
+        e32 = float((res["fp32"][2][n].double() - g64).abs().max()) / scale
+        rows.append((e3, e32, n, scale))
+        worst3, worst32 = max(worst3, e3), max(worst32, e32)
+    for e3, e32, n, scale in sorted(rows, reverse=True)[:6]:
+        print("   %-40s against fp64: split %.3e  fp32 instruction %.3e  (largest entry %.3e)" % (n, e3, e32, scale))
+    print(".whole step: loss %.9f (split) %.9f (fp32 instruction) %.9f (fp64); worst gradient error split %.3e, fp32 instruction %.3e" %
+          (res["split"][1], res["fp32"][1], float(loss64), worst3, worst32))
+    # Both paths carry the rounding noise of everything upstream of a gradient (fp32 activations, BatchNorm sums): per tensor the two
+    # errors are two draws of the same noise (Up0.conv.weight 1.5e-2 split against 2.4e-2, PB_1.Conv2.conv.weight 1.6e-2 against
+    # 0.8e-2), so the comparison is statistical -- the worst tensor, the geometric mean of the per-tensor ratios, and a loose per-tensor cap.
+    import math
+    ratios = [math.log((e3 + 1e-9) / (e32 + 1e-9)) for e3, e32, n, scale in rows]
+    gmean = math.exp(sum(ratios) / len(ratios))
+    print(".geometric mean of (split error / fp32-instruction error) over %d parameter tensors: %.3f" % (len(rows), gmean))
+    assert worst3 <= 1.25 * worst32 + 1e-5, (worst3, worst32)
+    assert gmean <= 1.15, gmean
+    for e3, e32, n, scale in rows:
+        assert e3 <= 3.0 * e32 + 1e-4, (n, e3, e32)
