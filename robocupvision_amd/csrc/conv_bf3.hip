@@ -356,7 +356,6 @@ static bool c3_geometry(const rcv_handle* h, const rcv_op* op, C3Geom* g) {
     if (S == 2 && WN != 5) continue;                             // (its five-set filter ring leaves registers for five pixel blocks)
     const int slots = 2 * WN * 16;
     for (int TW = 4; TW <= Wo && TW <= 64; ++TW) {
-      if (TW != Wo && ceil_div(Wo, TW) == ceil_div(Wo, TW - 1) && TW > 4) { /* a narrower tile covers the row with as many tiles */ }
       int TH = slots / TW;
       if (TH > Ho) TH = Ho;
       if (TH < 1) continue;
