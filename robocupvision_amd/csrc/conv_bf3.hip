@@ -213,7 +213,9 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(const ConvArgs a) {
     }
     __syncthreads();
   }
-  if (!(a.flags & RCV_F_DBG_NOEPI)) conv_epilogue<WM, WN, 2, 2, KIND_GATHER>(a, ti, acc, red, tid);
+  // (EB = 5: the residual / BatchNorm-backward operands of five pixel blocks are requested in one batch -- loaded where they are used they are
+  // serialized HBM round trips in the tail of the data-gradient launches)
+  if (!(a.flags & RCV_F_DBG_NOEPI)) conv_epilogue<WM, WN, 2, 2, KIND_GATHER, 5>(a, ti, acc, red, tid);
   else if (a.stats != RCV_STATS_NONE) __syncthreads();
 }
 
