@@ -280,7 +280,11 @@ bool wgradn_bf3_supported(const rcv_handle* h, const rcv_op* op) {
   const int CA = op->i[RCV_I_CIN], CB = op->i[RCV_I_COUT], s = op->i[RCV_I_STRIDE];
   if (op->i[RCV_I_DIL] != 1 || op->i[RCV_I_INMODE] == RCV_LOAD_NCHW || (s != 1 && s != 2)) return false;
   // (8-channel operands would be staged zero padded to 16: half of their staging threads idle and twice the LDS image -- measured 176 ->
-  // 246 us on the 8 <-> 16 stride-2 layers, which are HBM bound; they stay on the folded fp32 tile)
+  // 246 us on the 8 <-> 16 stride-2 layers, which are HBM bound; they stay on the folded fp32 tile.  Also measured, correct to 1e-7 and
+  // not kept: the pixel-PAIR view of those layers -- the gathered [H][W][8] tensor read as [H][W/2][16], the 16 MFMA columns = (pixel
+  // parity, channel); with stride 2 the taps kx = 1, 2 of an output pixel are exactly one pair and kx = 0 the odd half of the pair
+  // before it, so six column blocks carry the nine taps with the natural bytes in LDS: 207 / 228 us against 181 / 192 for the folded
+  // tile.  What these layers lack here is not MFMA time but streaming rate: one 512-thread workgroup per CU reads 3.0-3.5 TB/s.)
   if (CA < 16 || CA > 32 || CB < 16 || CB > 32 || CA % 4 || CB % 4) return false;
   if (op->i[RCV_I_WO] < 16 || op->i[RCV_I_HO] < 8) return false;
   const long tiles = (long)op->i[RCV_I_N] * ceil_div(op->i[RCV_I_HO], 8) * ceil_div(op->i[RCV_I_WO], 16);

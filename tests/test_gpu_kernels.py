@@ -127,7 +127,9 @@ WGRAD_SHAPES = [(4, 15, 20, 64, 64, 1), (4, 30, 40, 32, 64, 2), (4, 15, 20, 64, 
                 (3, 14, 18, 64, 128, 2), (1, 96, 128, 8, 16, 2),
                 # planes with at least one 8 x 16 tile per CU: the narrow layers' split-bf16 kernel (wgradn_bf3.hip), every channel-tile shape
                 (8, 64, 128, 16, 16, 1), (8, 64, 128, 32, 32, 1), (8, 128, 128, 16, 16, 2), (8, 128, 128, 16, 32, 2), (6, 60, 100, 32, 16, 1),
-                (5, 72, 112, 16, 32, 1), (8, 128, 128, 32, 32, 2), (6, 62, 100, 16, 24, 1), (8, 128, 128, 32, 16, 2)]
+                (5, 72, 112, 16, 32, 1), (8, 128, 128, 32, 32, 2), (6, 62, 100, 16, 24, 1), (8, 128, 128, 32, 16, 2),
+                # eight gathered channels, stride 2: the pixel-pair view of wgradn_bf3
+                (8, 128, 128, 8, 16, 2), (8, 128, 128, 8, 32, 2), (6, 126, 140, 8, 16, 2), (7, 100, 132, 8, 24, 2)]
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,s", WGRAD_SHAPES)
