@@ -155,13 +155,23 @@ __global__ __launch_bounds__(512) void wgradn_bf3_kernel(const WgradArgs a) {
         default: if constexpr (!GTWO) w3_store<RCV_LOAD_GRAD_DEC, G::PPIX, G::TW, CBT, !GTWO, true>(rp, a.p_c, pi, tid, a.CB, bsum); break;
       }
     };
-    // barrier for barrier the consumer path: 1 + one per tile + the bias partial's two
-    if (wg < a.ntiles) stage(wg, smem_w3);
+    // barrier for barrier the consumer path: 1 + one per tile + the bias partial's two.
+    // What bounds this kernel on the layers whose filter gradient is an HBM stream (16 channels on a side), by ablation at 16 -> 16
+    // (scripts/experiments/exp_r3_w3abl.sh): 138 us as it is, 101 with every load replaced by one cached element (same instructions, no
+    // HBM traffic), 88 with the MFMAs removed as well -- the staging instruction stream itself.  Load transform 4, split 5.5, bounds /
+    // addresses / bias sum ~5 vector instructions per ELEMENT: 2 320 channel quads x 60 instructions per tile = 2 200 cycles of the CU's
+    // four SIMDs at full rate, twice that as one wave per SIMD issues them.  Tried on that evidence and not kept: a second register set
+    // of loads in flight (0.147 -> 0.144 ms), a straight-line producer loop with the modes resolved outside it (same), SHARED roles --
+    // all eight waves stage and contract, loads of the next tile in flight during the contraction (0.140 -> 0.132 ms at 16 -> 16; its
+    // no-HBM, no-MFMA floor is still 74 us).  In this arithmetic such a layer is vector-ALU bound at ~1.5 x its HBM time; the fp32
+    // kernels stage with 4-5 instructions per element and stay the faster ones where the matrix pipe is not the limit.
+    const bool do_stage = !(a.dbg & RCV_F_DBG_NOSTAGE);           // (ablation timings: scripts/bench_op.py --flags)
+    if (wg < a.ntiles && do_stage) stage(wg, smem_w3);
     __syncthreads();
     int it = 0;
     for (int tile = wg; tile < a.ntiles; tile += gridDim.x, ++it) {
       const int next = tile + gridDim.x;
-      if (next < a.ntiles) stage(next, smem_w3 + ((it + 1) & 1) * G::BUF);
+      if (next < a.ntiles && do_stage) stage(next, smem_w3 + ((it + 1) & 1) * G::BUF);
       __syncthreads();
     }
     // bias partial: sum over the staging threads that hold the same channel quad (fixed order); the workgroup's row is that of its
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(512) void wgradn_bf3_kernel(const WgradArgs a) {
   {
     int it = 0;
     for (int tile = wg; tile < a.ntiles; tile += gridDim.x, ++it) {
-      contract(lds0 + (it & 1) * G::BUF);
+      if (!(a.dbg & RCV_F_DBG_NOMFMA)) contract(lds0 + (it & 1) * G::BUF);
       __syncthreads();
     }
   }
