@@ -356,6 +356,7 @@ static bool c3_geometry(const rcv_handle* h, const rcv_op* op, C3Geom* g) {
   bool found = false;
   for (int WN : {10, 5}) {
     if (S == 2 && WN != 5) continue;                             // (its five-set filter ring leaves registers for five pixel blocks)
+    if (const char* ev = RCV_ENV("RCV_BF3_WN")) { if (atoi(ev) != WN && S == 1) continue; }      // experiments build: force the tile size
     const int slots = 2 * WN * 16;
     for (int TW = 4; TW <= Wo && TW <= 64; ++TW) {
       int TH = slots / TW;
