@@ -398,6 +398,10 @@ bool conv_bf3_wanted(const rcv_handle* h, const rcv_op* op) {
     if (m == RCV_LOAD_GRAD_ENC || m == RCV_LOAD_GRAD_DEC) return false;
   }
   if ((long long)N * H * W * Cin >= (1ll << 31)) return false;
+  if (RCV_ENV("RCV_BF3_FWD")) {        // experiments build: forward launches only (what the two-stream step makes of the backward ones)
+    const int m = op->i[RCV_I_INMODE];
+    if (m == RCV_LOAD_GRAD_ENC || m == RCV_LOAD_GRAD_DEC) return false;
+  }
   C3Geom g;
   if (!c3_geometry(h, op, &g)) return false;
   // the grid must cover most of the chip (one 512-thread workgroup per CU): small planes stay on the other kernels

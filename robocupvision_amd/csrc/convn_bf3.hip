@@ -383,6 +383,10 @@ bool convn_bf3_wanted(const rcv_handle* h, const rcv_op* op) {
   if (!n3_geometry(h, op, kind, &g)) return false;
   if ((long)g.total * 2 < (long)h->num_cus) return false;   // small planes stay on the other kernels
   if (RCV_ENV("RCV_BF3N_ALL")) return true;
+  if (RCV_ENV("RCV_BF3N_FWD")) {       // experiments build: forward launches only
+    const int m0 = op->i[RCV_I_INMODE];
+    if (m0 == RCV_LOAD_GRAD_ENC || m0 == RCV_LOAD_GRAD_DEC) return false;
+  }
   // Where this kernel is the faster one (op by op at the shapes of the 640 x 480 step, scripts/experiments/exp_r3_n3ops.sh): the layers
   // whose fp32 form is matrix-pipe bound -- 32 -> 32 (133 -> 86 us forward, 157 -> 107 data gradient), 16 -> 16 (136 -> 125, 186 -> 170),
   // the 32 -> 16 transposed conv with a two-tensor input (202 -> 178).  The HBM-bound forms (8 -> 16 stride 2, the forward transposed
